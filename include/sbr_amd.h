@@ -1,0 +1,157 @@
+/*
+ * sbr_amd.h - C ABI of the MI355X-native batched SBR environment (libsbr_amd.so).
+ *
+ * Drop-in boundary for ONE path of SungKu/gym-SBR2: the step-level env `SBROS-v1`
+ * (gym_SBR/envs/gym_SBR_oneshot.py::SbrOS; registered at gym_SBR/__init__.py:11).  The
+ * reference has no FFI - its boundary is the gym.Env protocol - so each entry point names the
+ * Python method it replaces.  All array arguments are DEVICE pointers (HIP, e.g.
+ * torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * No torch types, no C++ types.  Every call returns 0 on success or a negative sbr_status; the
+ * message is available from sbr_last_error().  Nothing here ever falls back to the CPU.
+ *
+ * Layouts
+ *   action  [N][2]  float32   (u_DO set-point, u_EC set-point)   gym_SBR_oneshot.py:843,862,898
+ *   obs     [N][18] OutT      obs_DO[9] ++ obs_EC[9]             gym_SBR_oneshot.py:1027-1114
+ *   state   [N][15] OutT      [t, x0..x13] / x_1_state           gym_SBR_oneshot.py:1020-1025
+ *   reward  [N]     OutT                                         module_reward_EQIOCI.py:4-115
+ *   done    [N]     uint8                                        gym_SBR_oneshot.py:1122-1124
+ *   OutT = float32 (cfg.out_f64 = 0, the RL path) or float64 (cfg.out_f64 = 1, parity checks).
+ *   Internal plant/controller state is float64, struct-of-arrays [field][N] (sbr_get_state).
+ */
+#ifndef SBR_AMD_H
+#define SBR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBR_NX 14          /* V Si Ss Xi Xs Xbh Xba Xp So Sno Snh Snd Xnd Salk (gym_SBR_oneshot.py:185-188) */
+#define SBR_NOBS 18
+#define SBR_NSTATE 15
+#define SBR_NACT 2
+#define SBR_NSCEN 8        /* influent scenarios, buffer_tank3.py:18-1197 */
+#define SBR_NSAMP 48       /* samples per influent series */
+#define SBR_NSERIES 14     /* 13 concentrations + flow q */
+#define SBR_KLA_HIST 10    /* Kla values the reward can look back on (current + 9) */
+/* controller/bookkeeping doubles per env exposed by sbr_get_state/sbr_set_state, in this order */
+#define SBR_NCTRL 26
+enum {
+    SBR_C_T = 0,           /* running time t (days)                     gym_SBR_oneshot.py:1357 */
+    SBR_C_SO_M1, SBR_C_SO_M2, SBR_C_SNO_M1, SBR_C_SNO_M2,   /* So[-1] So[-2] Sno[-1] Sno[-2]  :1959-1961 */
+    SBR_C_IE_DO, SBR_C_IE_EC,                               /* PID integrals                  :1893,:1923 */
+    SBR_C_KLA_LAST, SBR_C_EC_LAST, SBR_C_EC_PREV,           /* Kla[-1], EC[-1], EC of interval before */
+    SBR_C_U_DO, SBR_C_U_EC,                                 /* set-points in force            :862-906 */
+    SBR_C_KLA_HIST0,                                        /* 10 entries, oldest first */
+    SBR_C_QW = SBR_C_KLA_HIST0 + SBR_KLA_HIST,              /* wastage flow of the last terminal step :2376 */
+    SBR_C_RETURN,                                           /* sum of rewards since reset */
+    SBR_C_STEPS,                                            /* step() calls since reset (as double) */
+    SBR_C_DONE                                              /* 1.0 once the episode ended */
+};
+
+typedef enum {
+    SBR_OK = 0,
+    SBR_ERR_INVALID = -1,      /* bad argument */
+    SBR_ERR_NO_DEVICE = -2,    /* no HIP device / wrong architecture */
+    SBR_ERR_HIP = -3,          /* a HIP runtime call failed */
+    SBR_ERR_ALLOC = -4
+} sbr_status;
+
+/* Every constant of the path.  sbr_default_config() fills in the reference's values
+ * (SURVEY.md Appendix A lists file:line for each). */
+typedef struct sbr_config {
+    /* ASM1 stoichiometry / kinetics                              gym_SBR_oneshot.py:116-119 */
+    double Ya, Yh, fp, ixb, ixp;
+    double muH, Ks, Koh, Kno, bH, eta_g, eta_h, kh, Kx, muA, Knh, bA, Koa, ka;
+    /* plant + time grid                                          gym_SBR_oneshot.py:25-37 */
+    double WV, IV, dt, t_delta, t_cycle;
+    double T_fill, T3_0, T3_end, T4_end, T5_end;      /* phase scalars, module_batch_time.py:3-116 */
+    double t_settle, t_draw;                          /* t_ratio[5], t_ratio[6] (fractions of t_cycle) */
+    /* controllers                                                gym_SBR_oneshot.py:80-96 */
+    double So_sat, Kla_min, Kla_max, Kc_DO, tauI_DO, tauD_DO;
+    double EC_min, EC_max, Kc_EC, tauI_EC, tauD_EC, EC_conc;
+    double act_DO_max, act_EC_max;                    /* action clipping :865-870, :901-906 */
+    /* terminal phases                                            gym_SBR_oneshot.py:123-124, :2189-2218 */
+    double biomass_setpoint, Qeff, settler_area, settler_vmax;
+    double x0[SBR_NX];                                /* episode start state :201-203 */
+    /* integrator */
+    int32_t substeps;          /* RK4 substeps per control interval (10 => h = dt) */
+    int32_t out_f64;           /* 0: obs/state/reward are float32; 1: float64 */
+    int32_t terminal;          /* 1: run settle/draw/idle on the done step (reference behaviour) */
+    int32_t auto_reset;        /* 0: a finished env ignores step() until sbr_reset (reference: caller resets) */
+} sbr_config;
+
+typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for N envs on one GPU */
+
+/* library / configuration ---------------------------------------------------------------- */
+const char* sbr_version(void);
+int sbr_default_config(sbr_config* cfg);
+int sbr_device_count(void);          /* HIP devices visible; 0 if none (never throws) */
+
+/* lifetime: replaces SbrOS.__init__ (gym_SBR_oneshot.py:103-166) for N instances.
+ * first_env_id: global id of local env 0 (multi-GPU sharding: RNG streams and scenario
+ * assignment depend on the GLOBAL id, so results do not depend on world size). */
+int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_config* cfg /* NULL = defaults */,
+               sbr_env** out);
+int sbr_destroy(sbr_env* env);
+const char* sbr_last_error(const sbr_env* env /* NULL = creation errors */);
+int64_t sbr_num_envs(const sbr_env* env);
+
+/* influent data: replaces the literals of buffer_tank3.py:18-1197.  means/stds are HOST pointers,
+ * [SBR_NSCEN][SBR_NSERIES][SBR_NSAMP] float64; copied to the device once. */
+int sbr_set_influent_tables(sbr_env* env, const double* means_host, const double* stds_host);
+
+/* reset: replaces SbrOS.reset() (gym_SBR_oneshot.py:168-438) = influent draw
+ * (buffer_tank3.py:68-107) + fill phase (Sim_filling :1585-1654) + reset observation.
+ *   scenario  [N] int32 or NULL (NULL = scenario 6 for every env, as the reference :180)
+ *   rnd       [N][48] float64 or NULL; NULL => drawn on the device: Philox4x32-10 keyed by `seed`,
+ *             subsequence = global env id, Box-Muller (the reference draws np.random.randn(48))
+ *   influent  [N][14] float64 or NULL; if given it REPLACES the draw (entry 0 is overwritten by
+ *             Qin/T_fill as at :287)
+ *   mask      [N] uint8 or NULL; if given only envs with mask != 0 are reset
+ *   obs       [N][18] OutT or NULL */
+int sbr_reset(sbr_env* env, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+              const uint8_t* mask, void* obs, void* stream);
+
+/* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
+ * one (at phase boundaries two) control interval(s) of RK4, reward, observations, and on the last
+ * call of an episode the settle/draw/idle phases.  Any of obs/state/reward/done may be NULL. */
+int sbr_step(sbr_env* env, const float* action, void* obs, void* state, void* reward, uint8_t* done,
+             void* stream);
+
+/* fused rollout with an on-device uniform random policy (BASELINE.json configs[4]): n_steps step()
+ * calls per env in ONE kernel, plant state held in registers; actions ~ U[0,act_DO_max] x
+ * U[0,act_EC_max] from Philox keyed by policy_seed, subsequence = global env id, counter = call index.
+ *   returns [N] float64 or NULL: sum of the rewards of these n_steps calls
+ *   actions_out [n_steps][N][2] float32 or NULL: the sampled actions (for replay through sbr_step) */
+int sbr_rollout(sbr_env* env, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out,
+                void* stream);
+
+/* batch statistics of a per-env float64 vector (e.g. episode returns): wavefront reductions
+ * + one atomic per wave.  out4 = {sum, min, max, count} float64, DEVICE pointer. */
+int sbr_reduce_stats(sbr_env* env, const double* values, int64_t n, double* out4, void* stream);
+
+/* parity injection / inspection: x is [SBR_NX][N], ctrl is [SBR_NCTRL][N], float64, DEVICE pointers. */
+int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
+int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
+
+/* standalone right-hand sides for known-answer tests (gym_SBR_oneshot.py:1658-1787, :1424-1583,
+ * :2424-2552).  x [n][14], kla [n], ec [n], loading [n][14] or NULL, dx [n][14]; DEVICE pointers.
+ * kind: 0 reaction, 1 filling (needs loading), 2 idle. */
+int sbr_eval_rhs(sbr_env* env, int32_t kind, int64_t n, const double* x, const double* kla, const double* ec,
+                 const double* loading, double* dx, void* stream);
+
+/* device-side normal draws used by sbr_reset when rnd == NULL, exposed for tests: out [N][48]. */
+int sbr_draw_normals(sbr_env* env, uint64_t seed, double* out, void* stream);
+
+/* timing helper for bench.py: average device time (ms) per sbr_step launch between two marks,
+ * measured with HIP events on `stream` (the stream the kernels are launched on). */
+int sbr_timer_start(sbr_env* env, void* stream);
+int sbr_timer_stop(sbr_env* env, void* stream, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBR_AMD_H */

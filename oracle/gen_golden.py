@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE; runs in the build container only).
+
+Imports the *unmodified* Python reference from /root/reference behind a ~30 line
+`gym` stand-in (the image has no `gym`), drives `SbrOS` (`SBROS-v1`,
+gym_SBR/envs/gym_SBR_oneshot.py:99) and records inputs + outputs as small fp64
+`.npz` fixtures under tests/golden/.  Nothing from the reference is copied: the
+fixtures hold numbers only (inputs, outputs, and the influent data tables that the
+reference keeps as literals in gym_SBR/envs/buffer_tank3.py:18-1197, captured from
+the running function's locals).
+
+The reference never travels to the GPU box; the tests there read the fixtures.
+
+Usage:  python oracle/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True  # never write __pycache__ into the read-only tree
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import numpy as np
+
+REF_ROOT = "/root/reference"
+
+
+# --------------------------------------------------------------------------- gym stand-in
+def install_gym_stub():
+    """Minimal `gym` so that `import gym_SBR.envs` resolves."""
+    if "gym" in sys.modules:
+        return
+    gym = types.ModuleType("gym")
+
+    class Env:  # noqa: D401 - stand-in
+        metadata = {}
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high)
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box = Box
+    envs = types.ModuleType("gym.envs")
+    registration = types.ModuleType("gym.envs.registration")
+    registry = {}
+
+    def register(id, entry_point=None, **kw):  # noqa: A002
+        registry[id] = entry_point
+
+    registration.register = register
+    registration.registry = registry
+    envs.registration = registration
+    gym.Env, gym.spaces, gym.envs = Env, spaces, envs
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.envs": envs,
+                        "gym.envs.registration": registration})
+
+
+def import_reference():
+    install_gym_stub()
+    import matplotlib
+    matplotlib.use("Agg")
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import gym_SBR.envs  # noqa: F401  (runs env0's import-time cycle)
+        import gym_SBR  # noqa: F401  registers the ten ids
+    from gym_SBR.envs import gym_SBR_oneshot as M
+    return M
+
+
+# --------------------------------------------------------------------------- influent tables
+SERIES = ["si", "ss", "xi", "xs", "xbh", "xba", "xp", "so", "sno", "snh", "snd", "xnd", "salk", "q"]
+
+
+def capture_influent_tables():
+    """Run buffer_tank(s) for s=0..7 and read the mean/std series from its locals."""
+    from gym_SBR.envs import buffer_tank3
+    fn = buffer_tank3.influent.buffer_tank
+    code = fn.__code__
+    means = np.zeros((8, 14, 48))
+    stds = np.zeros((8, 14, 48))
+    grabbed = {}
+
+    def tracer(frame, event, arg):
+        if frame.f_code is not code:
+            return None
+
+        def local(frame, event, arg):
+            if event == "return":
+                grabbed.update(frame.f_locals)
+            return local
+        return local
+
+    for s in range(8):
+        grabbed.clear()
+        sys.settrace(tracer)
+        try:
+            fn(s)
+        finally:
+            sys.settrace(None)
+        for j, name in enumerate(SERIES):
+            means[s, j, :] = np.broadcast_to(np.asarray(grabbed[name + "_m"], dtype=np.float64), (48,))
+            stds[s, j, :] = np.broadcast_to(np.asarray(grabbed[name + "_s"], dtype=np.float64), (48,))
+    return means, stds
+
+
+def influent_kats(n_seeds=4):
+    from gym_SBR.envs import buffer_tank3
+    fn = buffer_tank3.influent.buffer_tank
+    scen, rnds, mixed, var = [], [], [], []
+    real_randn = np.random.randn
+    for s in range(8):
+        for seed in range(n_seeds):
+            box = {}
+
+            def fake_randn(*a, _seed=seed, _s=s, _box=box):
+                rs = np.random.RandomState(1000 * _s + _seed)
+                r = rs.randn(*a) if _seed > 0 else np.zeros(a)
+                _box["rnd"] = r
+                return r
+
+            np.random.randn = fake_randn
+            try:
+                _, m, v = fn(s)
+            finally:
+                np.random.randn = real_randn
+            scen.append(s)
+            rnds.append(box["rnd"])
+            mixed.append(np.asarray(m, dtype=np.float64))
+            var.append(np.asarray([np.broadcast_to(np.asarray(c, dtype=np.float64), (48,)) for c in v]))
+    return (np.asarray(scen, dtype=np.int32), np.asarray(rnds), np.asarray(mixed), np.asarray(var))
+
+
+# --------------------------------------------------------------------------- RHS known answers
+def rhs_kats(M, n=96, seed=7):
+    env = M.SbrOS()
+    rs = np.random.RandomState(seed)
+    scale = np.array([1.32, 30, 30, 1500, 150, 3000, 2000, 600, 8, 20, 20, 10, 10, 10.0])
+    X = np.empty((n, 14))
+    X[:, 0] = rs.uniform(0.6, 1.4, n)
+    X[:, 1:] = scale[1:] * rs.uniform(0.02, 1.5, (n, 13))
+    # a few hard cases: oxygen/nitrate nearly zero (and slightly negative So as seen in the reference)
+    X[:8, 8] = [0.0, 1e-14, -7.7e-14, 1e-9, 1e-6, 1e-3, 8.0, 1e-52][:8]
+    X[8:12, 9] = [0.0, 1e-8, 1e-4, 1e-12]
+    kla = rs.choice([0.0, 60.0, 160.97, 240.0], n)
+    ec = rs.choice([0.0, 5e-4, 1.234e-4], n)
+    x0 = np.array([0.6161484733495801, 30, 0.571098000538576, 1440.01157895393, 31.254221999137,
+                   2599.2714348941, 168.915006750837, 551.901552960823, 2.16607843793004,
+                   13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
+                   3.790463057094611])
+    X[12] = x0
+    kla[12], ec[12] = 100.0, 0.0
+    loading = np.empty((n, 14))
+    loading[:, 0] = rs.uniform(20, 40, n)
+    loading[:, 1:] = np.array([30, 60, 50, 200, 28, 0, 0, 0, 0, 30, 6, 10, 7.0]) * rs.uniform(0.5, 1.5, (n, 13))
+    dreact = np.empty((n, 14))
+    dfill = np.empty((n, 14))
+    didle = np.empty((n, 14))
+    for i in range(n):
+        dreact[i] = env.reaction_dxdt(X[i].copy(), 0.0, env.Spar, env.Kpar, M.DO_control_par,
+                                      M.EC_control_par, kla[i], ec[i])
+        # filling_dxdt mutates x in place when EC != 0; the path only ever calls it with EC = 0
+        dfill[i] = env.filling_dxdt(X[i].copy(), 0.0, env.Spar, env.Kpar, M.DO_control_par,
+                                    M.EC_control_par, kla[i], 0.0, loading[i])
+        didle[i] = env.idle_dxdt(X[i].copy(), 0.0, env.Spar, env.Kpar, env.DO_control_par, kla[i])
+    return dict(X=X, kla=kla, ec=ec, loading=loading, d_reaction=dreact, d_filling=dfill, d_idle=didle,
+                So_sat=np.float64(M.DO_control_par[10]), EC_conc=np.float64(M.EC_conc),
+                Spar=np.asarray(env.Spar, dtype=np.float64), Kpar=np.asarray(env.Kpar, dtype=np.float64))
+
+
+# --------------------------------------------------------------------------- episodes
+def run_episode(M, seed, actions, rnd_override=None):
+    """One SbrOS episode; returns a dict of arrays (per call, per interval, terminal)."""
+    env = M.SbrOS()
+    rec = {}
+    box = {}
+    real_randn = np.random.randn
+
+    def spy_randn(*a):
+        r = real_randn(*a) if rnd_override is None else np.asarray(rnd_override, dtype=np.float64).copy()
+        box["rnd"] = np.array(r, dtype=np.float64)
+        return r
+
+    # --- per-interval spies on the two interval runners
+    intervals = []
+
+    def wrap(name, kind):
+        orig = getattr(env, name)
+
+        def inner(t, u_DO, u_EC, u_biomass, x_in, influent_mixed, done):
+            out = orig(t, u_DO, u_EC, u_biomass, x_in, influent_mixed, done)
+            t_new, x_out, _, _, t_range = out
+            intervals.append(dict(kind=kind, t_start=float(t), t_end=float(t_new), u_DO=float(u_DO),
+                                  u_EC=float(u_EC), x_start=np.array(x_in, dtype=np.float64),
+                                  x_rows=np.array(x_out, dtype=np.float64),
+                                  t_rows=np.array(t_range, dtype=np.float64),
+                                  Kla=float(M.Kla[-1]), EC=float(M.EC[-1]),
+                                  ie_DO=float(M.ie_DO[-1]), ie_EC=float(M.ie_EC[-1]),
+                                  call=len(calls) - 1))
+            return out
+        setattr(env, name, inner)
+
+    calls = []
+    wrap("run_anaero_step", 0)
+    wrap("run_aero_step", 1)
+
+    # --- terminal spies
+    term = {}
+    orig_sd = env.Sim_Settling_Drawing
+
+    def spy_sd(x, t, t_settling, t_drawing, dt_, Qeff, biomass_setpoint, EC):
+        out = orig_sd(x, t, t_settling, t_drawing, dt_, Qeff, biomass_setpoint, EC)
+        term["x_pre_settle"] = np.array(x, dtype=np.float64)
+        term["x_after_draw"] = np.array(out[0][-1], dtype=np.float64)
+        term["t_after_draw"] = np.float64(out[1][-1])
+        term["Qw"] = np.float64(out[2])
+        term["PE"] = np.float64(out[3])
+        term["SP"] = np.float64(out[4])
+        term["sX_eff"] = np.float64(M.sX_eff)
+        term["waste_sX_weight"] = np.float64(M.waste_sX_weight)
+        return out
+    env.Sim_Settling_Drawing = spy_sd
+    orig_idle = env.Sim_idle
+
+    def spy_idle(x, t_range, t_idle, u_DO, Kla, So, Ss, Sno, dcv_DO, ie_DO, e_DO, EC):
+        out = orig_idle(x, t_range, t_idle, u_DO, Kla, So, Ss, Sno, dcv_DO, ie_DO, e_DO, EC)
+        term["x_after_idle"] = np.array(out[0][-1], dtype=np.float64)
+        term["t_idle_start"] = np.float64(out[1][0])
+        term["t_idle_end"] = np.float64(out[1][-1])
+        term["n_idle_rows"] = np.int64(len(out[1]))
+        term["Kla_idle"] = np.float64(out[2][-1])
+        term["ie_DO_idle"] = np.float64(out[7][-1])
+        term["u_DO_idle"] = np.float64(u_DO)
+        return out
+    env.Sim_idle = spy_idle
+
+    np.random.seed(seed)
+    np.random.randn = spy_randn
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            obs0 = env.reset()
+    finally:
+        np.random.randn = real_randn
+    rec["seed"] = np.int64(seed)
+    rec["rnd"] = box["rnd"]
+    rec["influent_mixed"] = np.array(M.influent_mixed, dtype=np.float64)  # [0] already = Qin/T_fill
+    rec["x0_init"] = np.array(M.x0_init, dtype=np.float64)
+    rec["x_postfill"] = np.array(M.x_out[-1], dtype=np.float64)
+    rec["n_fill_rows"] = np.int64(len(M.x_out))
+    rec["t_postfill"] = np.float64(M.t)
+    rec["reset_obs_DO"] = np.array(obs0[0], dtype=np.float64)
+    rec["reset_obs_EC"] = np.array(obs0[1], dtype=np.float64)
+    rec["reset_Kla_tail"] = np.array(M.Kla[-9:], dtype=np.float64)
+    rec["reset_EC_tail"] = np.array(M.EC[-9:], dtype=np.float64)
+    rec["reset_len_Kla"] = np.int64(len(M.Kla))
+    rec["reset_len_EC"] = np.int64(len(M.EC))
+    rec["reset_So"] = np.array(M.So, dtype=np.float64)
+    rec["reset_Sno"] = np.array(M.Sno, dtype=np.float64)
+    rec["reset_ie_DO"] = np.float64(M.ie_DO[-1])
+    rec["reset_ie_EC"] = np.float64(M.ie_EC[-1])
+
+    keys = ["t", "x_start", "x_end", "Kla", "EC", "ie_DO", "ie_EC", "So_m1", "So_m2", "Sno_m1", "Sno_m2",
+            "reward", "r_EQI2", "r_OCI2", "r_AE2", "r_EC2", "obs_DO", "obs_EC", "state", "done", "n_intervals"]
+    per = {k: [] for k in keys}
+    done = False
+    k = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        while not done:
+            a = actions[k]
+            n_before = len(intervals)
+            calls.append(k)
+            obs, state, reward, done, _ = env.step([float(a[0]), float(a[1])])
+            n_iv = len(intervals) - n_before
+            last = intervals[-1]
+            per["t"].append(M.t)
+            per["x_start"].append(last["x_rows"][0])
+            per["x_end"].append(last["x_rows"][-1])
+            per["Kla"].append(last["Kla"])
+            per["EC"].append(last["EC"])
+            per["ie_DO"].append(last["ie_DO"])
+            per["ie_EC"].append(last["ie_EC"])
+            # controller memory as it stood right after the last reaction interval of this call
+            # (on the done call So/Sno have been extended by the terminal phases; recorded separately)
+            per["So_m1"].append(M.So[-1] if not done else np.nan)
+            per["So_m2"].append(M.So[-2] if not done else np.nan)
+            per["Sno_m1"].append(M.Sno[-1] if not done else np.nan)
+            per["Sno_m2"].append(M.Sno[-2] if not done else np.nan)
+            per["reward"].append(reward)
+            per["r_EQI2"].append(M.reward_EQI_t[-1])
+            per["r_OCI2"].append(M.reward_OCI_t[-1])
+            per["r_AE2"].append(M.reward_AE_t[-1])
+            per["r_EC2"].append(M.reward_EC_t[-1])
+            per["obs_DO"].append(obs[0])
+            per["obs_EC"].append(obs[1])
+            per["state"].append(state)
+            per["done"].append(done)
+            per["n_intervals"].append(n_iv)
+            k += 1
+    for kk in keys:
+        rec["step_" + kk] = np.asarray(per[kk], dtype=np.float64 if kk not in ("done", "n_intervals") else np.int64)
+    rec["actions"] = np.asarray(actions[:k], dtype=np.float64)
+    rec["n_calls"] = np.int64(k)
+    rec["iv_kind"] = np.asarray([iv["kind"] for iv in intervals], dtype=np.int64)
+    rec["iv_call"] = np.asarray([iv["call"] for iv in intervals], dtype=np.int64)
+    for f in ("t_start", "t_end", "u_DO", "u_EC", "Kla", "EC", "ie_DO", "ie_EC"):
+        rec["iv_" + f] = np.asarray([iv[f] for iv in intervals], dtype=np.float64)
+    rec["iv_x_start"] = np.asarray([iv["x_start"] for iv in intervals])
+    # the reference's output grid has int(((t+t_delta)-t)/dt) = 9 OR 10 rows, depending on the fp
+    # rounding of (t+t_delta)-t in t's binade (gym_SBR_oneshot.py:1339,1384): keep the count and
+    # NaN-pad the rows to 10.
+    n_rows = np.asarray([len(iv["t_rows"]) for iv in intervals], dtype=np.int64)
+    x_rows = np.full((len(intervals), 10, 14), np.nan)
+    t_rows = np.full((len(intervals), 10), np.nan)
+    for i, iv in enumerate(intervals):
+        x_rows[i, :n_rows[i]] = iv["x_rows"]
+        t_rows[i, :n_rows[i]] = iv["t_rows"]
+    rec["iv_n_rows"] = n_rows
+    rec["iv_x_rows"] = x_rows
+    rec["iv_t_rows"] = t_rows
+    rec["iv_x_end"] = np.asarray([iv["x_rows"][-1] for iv in intervals])
+    for kk, v in term.items():
+        rec["term_" + kk] = v
+    rec["episode_return"] = np.float64(np.sum(rec["step_reward"]))
+    traj = env.trajectory()
+    rec["traj_len_t_t"] = np.int64(len(traj[0]))
+    rec["traj_len_x_t"] = np.int64(len(traj[1]))
+    rec["traj_So_t"] = np.asarray(traj[5], dtype=np.float64)
+    rec["traj_Sno_t"] = np.asarray(traj[8], dtype=np.float64)
+    rec["traj_Snh_t"] = np.asarray(traj[17], dtype=np.float64)
+    rec["traj_t_t"] = np.asarray(traj[0], dtype=np.float64)
+    return rec
+
+
+def phase_constants(M):
+    return dict(T1_end=np.float64(M.t_memory1[-1]), T3_0=np.float64(M.t_memory3[0]),
+                T3_end=np.float64(M.t_memory3[-1]), T4_end=np.float64(M.t_memory4[-1]),
+                T5_end=np.float64(M.t_memory5[-1]),
+                lens=np.asarray([len(m) for m in (M.t_memory1, M.t_memory2, M.t_memory3, M.t_memory4,
+                                                  M.t_memory5, M.t_memory6, M.t_memory7, M.t_memory8)]),
+                dt=np.float64(M.dt), t_delta=np.float64(M.t_delta), t_cycle=np.float64(M.t_cycle),
+                t_ratio=np.asarray(M.t_ratio, dtype=np.float64),
+                So_sat=np.float64(M.DO_control_par[10]),
+                DO_control_par=np.asarray(M.DO_control_par, dtype=np.float64),
+                EC_control_par=np.asarray(M.EC_control_par, dtype=np.float64),
+                EC_conc=np.float64(M.EC_conc))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    M = import_reference()
+
+    np.savez_compressed(os.path.join(out, "constants.npz"), **phase_constants(M))
+    means, stds = capture_influent_tables()
+    np.savez_compressed(os.path.join(out, "influent_tables.npz"), means=means, stds=stds,
+                        series=np.asarray(SERIES))
+    scen, rnds, mixed, var = influent_kats()
+    np.savez_compressed(os.path.join(out, "influent_kat.npz"), scenario=scen, rnd=rnds, mixed=mixed, var=var)
+    np.savez_compressed(os.path.join(out, "rhs_kat.npz"), **rhs_kats(M))
+
+    rs = np.random.RandomState(123)
+    n = 470
+    cases = {
+        "const_2_5": (0, np.tile([2.0, 5.0], (n, 1)), None),
+        "random_a": (1, np.column_stack([rs.uniform(0, 8, n), rs.uniform(0, 15, n)]), None),
+        "random_b": (2, np.column_stack([rs.uniform(-2, 10, n), rs.uniform(-5, 20, n)]), None),  # exercises clipping
+        "zeros": (3, np.zeros((n, 2)), None),
+        "max": (4, np.tile([8.0, 15.0], (n, 1)), None),
+        "det_influent": (5, np.tile([1.5, 3.0], (n, 1)), np.zeros(48)),  # rnd = 0 (config 2 style)
+    }
+    for name, (seed, acts, rnd) in cases.items():
+        rec = run_episode(M, seed, acts, rnd)
+        np.savez_compressed(os.path.join(out, "sbros_%s.npz" % name), **rec)
+        print("%-14s calls=%d intervals=%d return=%.16g Qw=%.16g" % (
+            name, rec["n_calls"], len(rec["iv_kind"]), rec["episode_return"], rec.get("term_Qw", np.nan)))
+    print("wrote fixtures to", out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,464 @@
+/*
+ * sbr_oracle.c - CPU oracle, layer 2 (TEST INFRASTRUCTURE, not product code).
+ *
+ * Plain-C, fp64 restatement of the SBROS-v1 path of SungKu/gym-SBR2
+ * (/root/reference/gym_SBR/envs/gym_SBR_oneshot.py::SbrOS) with the fixed-step RK4 integrator
+ * that the HIP kernels use (10 substeps per control interval) in place of SciPy's LSODA.
+ * Each function cites the reference lines it follows.  It is pinned by tests/test_oracle_golden.py
+ * against the tests/golden fixtures (captured from the running reference by oracle/gen_golden.py) and
+ * against oracle/sbr_ref.py (same algorithm with the reference's own LSODA).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (libsbr_amd.so) never links, loads or calls it.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define NX 14
+#define KLA_HIST 10
+
+typedef struct {
+    double Ya, Yh, fp, ixb, ixp;
+    double muH, Ks, Koh, Kno, bH, eta_g, eta_h, kh, Kx, muA, Knh, bA, Koa, ka;
+    double WV, IV, dt, t_delta, t_cycle;
+    double T_fill, T3_0, T3_end, T4_end, T5_end;
+    double t_settle, t_draw;
+    double So_sat, Kla_min, Kla_max, Kc_DO, tauI_DO, tauD_DO;
+    double EC_min, EC_max, Kc_EC, tauI_EC, tauD_EC, EC_conc;
+    double act_DO_max, act_EC_max;
+    double biomass_setpoint, Qeff, settler_area, settler_vmax;
+    double x0[NX];
+    int32_t substeps, out_f64, terminal, auto_reset;
+} sbro_params;
+
+/* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
+typedef struct {
+    double x[NX];
+    double t;
+    double so_m1, so_m2, sno_m1, sno_m2;
+    double ie_do, ie_ec;
+    double kla_last, ec_last, ec_prev;
+    double u_do, u_ec;
+    double kla_hist[KLA_HIST];      /* oldest first; [KLA_HIST-1] is the current interval's Kla */
+    double qw, ret, steps, done;
+    double influent[NX];            /* loading vector, [0] = Qin/T_fill */
+    double x_start[NX];             /* start state of the last interval (for xdot) */
+    double span;                    /* t_range[-1]-t_range[0] of the last interval */
+    int32_t n_rows;                 /* 9 or 10: len(t_range) of the last interval */
+    int32_t n_intervals;            /* intervals run by the last step() call */
+} sbro_env;
+
+static const double X1_STATE[15] = {0.5, 1.32, 30, 30, 1500, 150, 3000, 2000, 600, 8, 20, 20, 10, 10, 10};
+
+/* ---------------------------------------------------------------------------------- defaults */
+void sbro_default_params(sbro_params* p) {
+    /* gym_SBR_oneshot.py:116-119 */
+    p->Ya = 0.24; p->Yh = 0.67; p->fp = 0.08; p->ixb = 0.08; p->ixp = 0.06;
+    p->muH = 4.0; p->Ks = 10.0; p->Koh = 0.2; p->Kno = 0.5; p->bH = 0.3; p->eta_g = 0.8; p->eta_h = 0.8;
+    p->kh = 3.0; p->Kx = 0.1; p->muA = 0.5; p->Knh = 1.0; p->bA = 0.05; p->Koa = 0.4; p->ka = 0.05;
+    /* :25-37, :197 */
+    p->WV = 1.32; p->IV = 0.6161484733495801; p->dt = 0.002 / 24; p->t_delta = p->dt * 10; p->t_cycle = 12.0 / 24;
+    /* module_batch_time.py:3-116, values asserted against tests/golden/constants.npz */
+    p->T_fill = 0.021; p->T3_0 = 0.06416666666666668; p->T3_end = 0.2516666666666667;
+    p->T4_end = 0.4085000000000001; p->T5_end = 0.40933333333333344;
+    p->t_settle = 8.3 / 100; p->t_draw = 2.1 / 100;
+    /* :80-96 ; So_sat = DO_set(15), module_temperature.py:3-20 */
+    p->So_sat = 8.000000000006622; p->Kla_min = 0; p->Kla_max = 240; p->Kc_DO = 100; p->tauI_DO = 20; p->tauD_DO = 0;
+    p->EC_min = 0; p->EC_max = 0.0005; p->Kc_EC = 100; p->tauI_EC = 20; p->tauD_EC = 0; p->EC_conc = 1200000 * 4.0;
+    p->act_DO_max = 8; p->act_EC_max = 15;
+    /* :123-124, :2189, :2211 */
+    p->biomass_setpoint = 2700; p->Qeff = 0.66; p->settler_area = (1.25 / 2) * (1.25 / 2); p->settler_vmax = 474;
+    static const double x0[NX] = {0.6161484733495801, 30, 0.571098000538576, 1440.01157895393, 31.254221999137,
+                                  2599.2714348941, 168.915006750837, 551.901552960823, 2.16607843793004,
+                                  13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
+                                  3.790463057094611};
+    memcpy(p->x0, x0, sizeof x0);
+    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->auto_reset = 0;
+}
+
+int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }
+int sbro_sizeof_params(void) { return (int)sizeof(sbro_params); }
+
+/* ---------------------------------------------------------------------------------- RHS */
+/* conversion rates r[1..13] incl. aeration: process rates :1660-1685, stoichiometry :1689-1725,
+ * combination :1731-1755 */
+static void conversion(const sbro_params* p, const double* x, double kla, double* r) {
+    const double ss = x[2], xs = x[4], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10], snd = x[11],
+                 xnd = x[12];
+    const double rho1 = p->muH * (ss / (p->Ks + ss)) * (so / (p->Koh + so)) * xbh;
+    const double rho2 = p->muH * (ss / (p->Ks + ss)) * (p->Koh / (so + p->Koh)) * (sno / (p->Kno + sno)) * p->eta_g * xbh;
+    const double rho3 = p->muA * (snh / (p->Knh + snh)) * (so / (p->Koa + so)) * xba;
+    const double rho4 = p->bH * xbh;
+    const double rho5 = p->bA * xba;
+    const double rho6 = p->ka * snd * xbh;
+    const double rho7 = p->kh * ((xs / xbh) / (p->Kx + (xs / xbh))) *
+                        ((so / (p->Koh + so)) + p->eta_h * (p->Koh / (so + p->Koh)) * (sno / (p->Kno + sno))) * xbh;
+    const double rho8 = (xnd / xs) * rho7;
+    const double Yh = p->Yh, Ya = p->Ya, ixb = p->ixb, ixp = p->ixp, fp = p->fp;
+    r[0] = 0; r[1] = 0; r[3] = 0;
+    r[2] = (-1 / Yh) * rho1 + (-1 / Yh) * rho2 + rho7;
+    r[4] = (1 - ixp) * rho4 + (1 - ixp) * rho5 + (-1.0) * rho7;
+    r[5] = rho1 + rho2 + (-1.0) * rho4;
+    r[6] = rho3 + (-1.0) * rho5;
+    r[7] = ixp * rho4 + ixp * rho5;
+    r[8] = (-(1 - Yh) / Yh) * rho1 + (-(4.57 - Ya) / Ya) * rho3 + kla * (p->So_sat - so);
+    r[9] = (-((1 - Yh) / (2.86 * Yh))) * rho2 + (1 / Ya) * rho3;
+    r[10] = (-ixb) * rho1 + (-ixb) * rho2 + (-ixb - 1 / Ya) * rho3 + rho6;
+    r[11] = (-1.0) * rho6 + rho8;
+    r[12] = (ixb - fp * ixp) * rho4 + (ixb - fp * ixp) * rho5 + (-1.0) * rho8;
+    r[13] = (-ixb / 14) * rho1 + ((1 - Yh) / (14 * 2.86 * Yh) - ixb / 14) * rho2 + (-ixb / 14 - 1 / (7 * Ya)) * rho3 +
+            (1.0 / 14) * rho6;
+}
+
+/* reaction_dxdt :1658-1787 */
+void sbro_rhs_reaction(const sbro_params* p, const double* x, double kla, double ec, double* d) {
+    double r[NX];
+    conversion(p, x, kla, r);
+    const double q = ec / x[0];
+    d[0] = 0 + ec;
+    for (int i = 1; i < NX; ++i) d[i] = r[i] + q * (i == 2 ? (p->EC_conc - x[i]) : (-x[i]));
+}
+
+/* filling_dxdt :1424-1583, EC = 0 (the only way the path calls it).  The reference's in-place
+ * dilution block :1523-1551 is then x[i] = (x[i]*V)/V - the identity up to 1 ulp - and is not restated. */
+void sbro_rhs_fill(const sbro_params* p, const double* x, double kla, const double* loading, double* d) {
+    double r[NX];
+    conversion(p, x, kla, r);
+    const double q = loading[0] / x[0];
+    d[0] = loading[0];
+    for (int i = 1; i < NX; ++i) d[i] = r[i] + q * (loading[i] - x[i]);
+}
+
+/* idle_dxdt :2424-2552 */
+void sbro_rhs_idle(const sbro_params* p, const double* x, double kla, double* d) {
+    double r[NX];
+    conversion(p, x, kla, r);
+    d[0] = 0;
+    for (int i = 1; i < NX; ++i) d[i] = r[i];
+}
+
+void sbro_eval_rhs(const sbro_params* p, int kind, int64_t n, const double* x, const double* kla, const double* ec,
+                   const double* loading, double* dx) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (kind == 0) sbro_rhs_reaction(p, x + i * NX, kla[i], ec[i], dx + i * NX);
+        else if (kind == 1) sbro_rhs_fill(p, x + i * NX, kla[i], loading + i * NX, dx + i * NX);
+        else sbro_rhs_idle(p, x + i * NX, kla[i], dx + i * NX);
+    }
+}
+
+/* classical RK4, n equal substeps over [0, span]; the systems are autonomous inside a span.
+ * kind 0: reaction(kla, ec)  1: fill(kla, loading)  2: idle(kla) */
+static void rk4_span(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,
+                     const double* loading) {
+    const double h = span / n;
+    double k1[NX], k2[NX], k3[NX], k4[NX], y[NX];
+    for (int s = 0; s < n; ++s) {
+#define F(in, out)                                                \
+    do {                                                          \
+        if (kind == 0) sbro_rhs_reaction(p, in, kla, ec, out);    \
+        else if (kind == 1) sbro_rhs_fill(p, in, kla, loading, out); \
+        else sbro_rhs_idle(p, in, kla, out);                      \
+    } while (0)
+        F(x, k1);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (0.5 * h) * k1[i];
+        F(y, k2);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (0.5 * h) * k2[i];
+        F(y, k3);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + h * k3[i];
+        F(y, k4);
+        for (int i = 0; i < NX; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+#undef F
+    }
+}
+
+void sbro_rk4(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,
+              const double* loading) {
+    rk4_span(p, kind, x, span, n, kla, ec, loading);
+}
+
+/* ---------------------------------------------------------------------------------- influent */
+/* buffer_tank3.py:68-107 for one scenario.  means/stds: [14][48] (row 13 = flow q). */
+void sbro_influent_mix(const double* means, const double* stds, const double* rnd, double* out) {
+    double q[48], sq = 0;
+    for (int k = 0; k < 48; ++k) q[k] = means[13 * 48 + k] + stds[13 * 48 + k] * rnd[k];
+    for (int k = 0; k < 48; ++k) sq = sq + q[k];
+    out[0] = 0.66;
+    for (int j = 0; j < 13; ++j) {
+        double s = 0;
+        for (int k = 0; k < 48; ++k) s = s + (means[j * 48 + k] + stds[j * 48 + k] * rnd[k]) * q[k];
+        out[1 + j] = s / sq;
+    }
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11), the generator sbr_reset uses on the device when no rnd
+ * vector is passed.  counter = (i, 0, env_lo, env_hi), key = (seed_lo, seed_hi). */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+static inline double u53(uint32_t hi, uint32_t lo) { /* (0,1] */
+    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+    return ((double)v + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+/* 48 standard normals for one env: Box-Muller on 24 Philox blocks (stream 0 = influent noise) */
+void sbro_draw_normals(uint64_t seed, uint64_t env_id, double* out) {
+    for (uint32_t i = 0; i < 24; ++i) {
+        uint32_t c[4] = {i, 0u, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double u1 = u53(c[0], c[1]), u2 = u53(c[2], c[3]);
+        const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925286766559 * u2;
+        out[2 * i] = rad * cos(ang);
+        out[2 * i + 1] = rad * sin(ang);
+    }
+}
+
+/* uniform random action of call `step` (stream 1 = policy) */
+void sbro_policy_action(const sbro_params* p, uint64_t seed, uint64_t env_id, uint32_t step, float* a) {
+    uint32_t c[4] = {step, 1u, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    a[0] = (float)(u53(c[0], c[1]) * p->act_DO_max);
+    a[1] = (float)(u53(c[2], c[3]) * p->act_EC_max);
+}
+
+/* ---------------------------------------------------------------------------------- observations */
+static double clip1(double v) { return v > 1 ? 1 : (v < -1 ? -1 : v); }
+
+/* obs_DO ++ obs_EC (:1027-1114); t_obs and x are what the observation reports, xa..xb the xdot span */
+static void build_obs(double t_obs, const double* xrep, const double* xa, const double* xb, double* obs) {
+    obs[0] = t_obs / 0.5; obs[1] = xrep[5] / 2000; obs[2] = xrep[6] / 500; obs[3] = xrep[8] / 8.; obs[4] = xrep[10] / 10;
+    obs[5] = clip1((xb[5] - xa[5]) / 4000); obs[6] = clip1((xb[6] - xa[6]) / 500);
+    obs[7] = clip1((xb[8] - xa[8]) / 8); obs[8] = clip1((xb[10] - xa[10]) / 50);
+    obs[9] = t_obs / 0.5; obs[10] = xrep[2] / 30; obs[11] = xrep[5] / 2000; obs[12] = xrep[9] / 10; obs[13] = xrep[10] / 10;
+    obs[14] = clip1((xb[2] - xa[2]) / 50); obs[15] = clip1((xb[5] - xa[5]) / 4000);
+    obs[16] = clip1((xb[9] - xa[9]) / 50); obs[17] = clip1((xb[10] - xa[10]) / 50);
+}
+
+static void build_state(double t_obs, const double* x, double* state) {
+    state[0] = t_obs / X1_STATE[0];
+    for (int i = 0; i < NX; ++i) state[1 + i] = x[i] / X1_STATE[1 + i];
+}
+
+/* ---------------------------------------------------------------------------------- reset */
+/* SbrOS.reset :168-438 with Sim_filling :1585-1654.  influent_in[14]: flow-weighted influent
+ * ([0] is overwritten by Qin/T_fill as at :287).  obs may be NULL. */
+void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, double* obs) {
+    const double qin = p->WV - p->IV;
+    memcpy(e->influent, influent_in, sizeof e->influent);
+    e->influent[0] = qin / p->T_fill;
+    memcpy(e->x, p->x0, sizeof e->x);
+    e->u_do = 0; e->u_ec = 15;
+    /* DO-PID at t_start == 0: ie = 0, dcv = 0, set-point 0 (:1593-1617) */
+    const double err = 0 - p->x0[8];
+    double ie = 0;
+    double kla = p->Kc_DO * err + p->Kc_DO / p->tauI_DO * ie + p->Kc_DO * p->tauD_DO * 0 + 0;
+    if (kla > p->Kla_max) { kla = p->Kla_max; ie = ie - err * p->dt; }
+    if (kla < p->Kla_min) { kla = p->Kla_min; ie = ie - err * p->dt; }
+    e->ie_do = ie; e->ie_ec = 0;
+    const double t_end = 0 + p->T_fill;                 /* t_ratio[0]*0.5 == T_fill */
+    const int n_rows = (int)((t_end - 0) / p->dt);      /* 252 */
+    double x0c[NX];
+    memcpy(x0c, e->x, sizeof x0c);
+    rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);
+    e->so_m2 = p->x0[8]; e->so_m1 = e->x[8];
+    e->sno_m2 = p->x0[9]; e->sno_m1 = e->x[2];          /* :1652 stores Ss in the Sno memory */
+    e->t = t_end;
+    /* Kla list = [0, kla] replicated (:323): the tail alternates, newest = kla */
+    for (int j = 0; j < KLA_HIST; ++j) e->kla_hist[j] = ((KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;
+    e->kla_last = kla; e->ec_last = 0; e->ec_prev = 0;
+    e->qw = 0; e->ret = 0; e->steps = 0; e->done = 0;
+    memcpy(e->x_start, x0c, sizeof x0c);
+    e->span = t_end; e->n_rows = n_rows; e->n_intervals = 0;
+    if (obs) {
+        /* volume blend of influent and post-fill state (:346-361) */
+        double xr[NX];
+        for (int i = 0; i < NX; ++i) xr[i] = (qin * e->influent[i] + e->x[i] * p->IV) / (qin + p->IV);
+        build_obs(e->t, xr, x0c, e->x, obs);
+    }
+}
+
+/* ---------------------------------------------------------------------------------- interval */
+/* Sim_aero_rxn :1877-1963 / Sim_anaero_rxn :1965-2051 + run_*_step :1331-1419 */
+static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
+    const double t0 = e->t, t1 = t0 + p->t_delta;
+    const int n_rows = (int)((t1 - t0) / p->dt);        /* 9 or 10, fp-dependent (:1339,:1384) */
+    /* DO PID */
+    const double sp = aerobic ? e->u_do : 0;
+    const double err = sp - e->so_m1;
+    const double dcv = (e->so_m1 - e->so_m2) / p->dt;
+    e->ie_do = e->ie_do + err * p->dt;
+    double kla = aerobic ? (p->Kc_DO * err + p->Kc_DO / p->tauI_DO * e->ie_do + p->Kc_DO * p->tauD_DO * dcv + e->kla_last) : 0;
+    if (kla > p->Kla_max) { kla = p->Kla_max; e->ie_do = e->ie_do - err * p->dt; }
+    if (kla < p->Kla_min) { kla = p->Kla_min; e->ie_do = e->ie_do - err * p->dt; }
+    /* NO3 PID (error sign reversed) */
+    const double err2 = e->sno_m1 - e->u_ec;
+    const double dcv2 = (e->sno_m1 - e->sno_m2) / p->dt;
+    e->ie_ec = e->ie_ec + err2 * p->dt;
+    double ec = aerobic ? 0 : (p->Kc_EC * err2 + p->Kc_EC / p->tauI_EC * e->ie_ec + p->Kc_EC * p->tauD_EC * dcv2 + e->ec_last);
+    if (ec < p->EC_min) { ec = p->EC_min; e->ie_ec = e->ie_ec - err2 * p->dt; }
+    else if (ec > p->EC_max) { ec = p->EC_max; e->ie_ec = e->ie_ec - err2 * p->dt; }
+    memcpy(e->x_start, e->x, sizeof e->x_start);
+    rk4_span(p, 0, e->x, t1 - t0, p->substeps, kla, ec, 0);
+    for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];
+    e->kla_hist[KLA_HIST - 1] = kla;
+    e->ec_prev = e->ec_last; e->ec_last = ec; e->kla_last = kla;
+    e->so_m2 = e->so_m1; e->so_m1 = e->x[8];
+    e->sno_m2 = e->sno_m1; e->sno_m1 = e->x[9];
+    e->t = t1; e->span = t1 - t0; e->n_rows = n_rows; e->n_intervals += 1;
+}
+
+/* module_reward_EQIOCI.py:4-115 */
+static double reward_of(const sbro_params* p, const sbro_env* e) {
+    const double* x = e->x;
+    const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
+    const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
+    const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
+    const double bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * (xbh + xba));
+    const double cod = x[2] + x[1] + xs + xi + xbh + xba + xp;
+    const double eqi = (2 * ss_ + 1 * cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
+    const double eqi2 = eqi / 10;
+    const double td = 0.002 / 24;
+    const int n = e->n_rows;
+    double ksum = 0;                                     /* Kla[-n:-1]: the n-1 values before the current */
+    for (int j = KLA_HIST - n; j < KLA_HIST - 1; ++j) ksum = ksum + e->kla_hist[j];
+    const double ae = 8 / (e->span * 1.8 * 1000) * (1.32 * ksum * td);
+    double esum = 0 + e->ec_prev;                        /* EC[-n:-1]: previous interval's last + (n-2) current */
+    for (int j = 0; j < n - 2; ++j) esum = esum + e->ec_last;
+    const double ec_oci = p->EC_conc * esum * td / (e->span * 1000);
+    const double oci = ae + ec_oci;
+    return (1 - (eqi2 * eqi2 + oci * oci)) / 473;
+}
+
+/* ---------------------------------------------------------------------------------- terminal */
+/* settle (:2171-2262, closed form of the linear layer system, see oracle/sbr_ref.py
+ * settle_closed_form), draw/waste (:2327-2393), idle (:2554-2597) */
+static void terminal(const sbro_params* p, sbro_env* e) {
+    double* x = e->x;
+    const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
+    const double vs = x[0], z = vs / p->settler_area;
+    const double t_set = p->t_settle * p->t_cycle;
+    const double a = p->settler_vmax / z * t_set, ea = exp(-a);
+    double sx[10], term = 1.0, partial = 0.0, others = 0.0;
+    for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= a / (j + 1); }
+    for (int j = 1; j < 10; ++j) others += sx[j];
+    sx[0] = 10.0 * xf - others;
+    const double t_after_draw = (e->t + t_set) + p->t_draw * p->t_cycle;
+    const double layer_v = vs / 10;
+    double resid_v = vs - p->Qeff;
+    int m = (int)ceil(nearbyint(p->Qeff / layer_v));     /* python round() = half-to-even */
+    if (m < 1) m = 1;
+    if (m > 9) m = 9;
+    double w[10], rs[10], wsum = 0;
+    for (int i = 0; i < 10 - m; ++i) { w[i] = layer_v * sx[i]; rs[i] = sx[i]; }
+    for (int i = 0; i < 10 - m; ++i) wsum = wsum + w[i];
+    double waste = wsum - p->biomass_setpoint * resid_v;
+    double qw = NAN;
+    for (int i = 0; i < 10 - m; ++i) {
+        const double rest = waste - w[i];
+        if (rest > 0) { waste = rest; rs[i] = 0; w[i] = 0; resid_v -= layer_v; }
+        else {
+            qw = waste / (rs[i] - p->biomass_setpoint);
+            w[i] = w[i] - qw * rs[i];
+            resid_v -= qw;
+            rs[i] = w[i] / (layer_v - qw);
+            break;
+        }
+    }
+    wsum = 0;
+    for (int i = 0; i < 10 - m; ++i) wsum = wsum + w[i];
+    const double sx2 = wsum / resid_v;
+    x[0] = resid_v;
+    for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
+    e->qw = qw;
+    /* idle: one DO-PID update (So[-1] == So[-2] == x[8] after settle/draw), then conversion only */
+    const double err = e->u_do - x[8];
+    e->ie_do = e->ie_do + err * p->dt;
+    double kla = p->Kc_DO * err + p->Kc_DO / p->tauI_DO * e->ie_do + p->Kc_DO * p->tauD_DO * 0.0 + e->kla_last;
+    if (kla > p->Kla_max) { kla = p->Kla_max; e->ie_do = e->ie_do - err * p->dt; }
+    if (kla < p->Kla_min) { kla = p->Kla_min; e->ie_do = e->ie_do - err * p->dt; }
+    const int n_rows = (int)((p->t_cycle - t_after_draw) / p->dt);
+    rk4_span(p, 2, x, p->t_cycle - t_after_draw, n_rows, kla, 0, 0);
+    e->kla_last = kla;
+}
+
+/* ---------------------------------------------------------------------------------- step */
+/* SbrOS.step :843-1273.  obs[18], state[15] may be NULL. */
+void sbro_step(const sbro_params* p, sbro_env* e, const double* action, double* obs, double* state, double* reward,
+               uint8_t* done) {
+    if (e->done != 0) {                                   /* finished env: wait for reset (reference: caller resets) */
+        if (reward) *reward = 0;
+        if (done) *done = 1;
+        if (obs) build_obs(p->t_cycle, e->x, e->x, e->x, obs);
+        if (state) build_state(p->t_cycle, e->x, state);
+        return;
+    }
+    double a0 = action[0], a1 = action[1];   /* float64, like the reference; the product takes float32 */
+    a0 = a0 < 0 ? 0 : (a0 > p->act_DO_max ? p->act_DO_max : a0);
+    a1 = a1 < 0 ? 0 : (a1 > p->act_EC_max ? p->act_EC_max : a1);
+    e->n_intervals = 0;
+    /* four sequential tests on the running time (:860, :896, :931, :963) */
+    if (e->t < p->T3_0) { e->u_ec = a1; e->u_do = 0; interval(p, e, 0); }
+    if (e->t >= p->T3_0 && e->t <= p->T3_end) { e->u_do = a0; e->u_ec = 0; interval(p, e, 1); }
+    if (e->t > p->T3_end && e->t <= p->T4_end) { e->u_ec = a1; e->u_do = 0; interval(p, e, 0); }
+    if (e->t > p->T4_end) { e->u_do = a0; e->u_ec = 0; interval(p, e, 1); }
+    const double r = reward_of(p, e);
+    e->ret += r; e->steps += 1;
+    double t_obs = e->t;
+    double xa[NX];
+    memcpy(xa, e->x_start, sizeof xa);
+    uint8_t dn = 0;
+    if (e->t >= p->T5_end) {                              /* :1122 */
+        dn = 1; e->done = 1;
+        if (p->terminal) { memcpy(xa, e->x, sizeof xa); terminal(p, e); t_obs = p->t_cycle; }
+    }
+    if (obs) build_obs(t_obs, e->x, xa, e->x, obs);
+    if (state) build_state(t_obs, e->x, state);
+    if (reward) *reward = r;
+    if (done) *done = dn;
+}
+
+/* ---------------------------------------------------------------------------------- batched */
+void sbro_batch_reset(const sbro_params* p, int64_t n, sbro_env* envs, const double* influent /* [n][14] */,
+                      double* obs /* [n][18] or NULL */, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) sbro_reset(p, envs + i, influent + i * NX, obs ? obs + i * 18 : 0);
+}
+
+void sbro_batch_step(const sbro_params* p, int64_t n, sbro_env* envs, const double* action, double* obs, double* state,
+                     double* reward, uint8_t* done, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        sbro_step(p, envs + i, action + 2 * i, obs ? obs + 18 * i : 0, state ? state + 15 * i : 0,
+                  reward ? reward + i : 0, done ? done + i : 0);
+}
+
+/* n_steps calls with the on-device random policy's actions (same Philox stream as sbr_rollout) */
+void sbro_batch_rollout(const sbro_params* p, int64_t n, sbro_env* envs, int64_t first_env_id, int32_t n_steps,
+                        uint64_t policy_seed, double* returns, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double acc = 0;
+        for (int32_t s = 0; s < n_steps; ++s) {
+            float a[2];
+            double r, ad[2];
+            const uint32_t call = (uint32_t)envs[i].steps;
+            sbro_policy_action(p, policy_seed, (uint64_t)(first_env_id + i), call, a);
+            ad[0] = a[0]; ad[1] = a[1];                 /* the device policy samples float32 actions */
+            sbro_step(p, envs + i, ad, 0, 0, &r, 0);
+            acc += r;
+        }
+        if (returns) returns[i] = acc;
+    }
+}

@@ -1,0 +1,157 @@
+"""ctypes front-end of oracle/sbr_oracle.c (TEST INFRASTRUCTURE - CPU oracle, layer 2).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libsbr_oracle.so")
+NX, NOBS, NSTATE, KLA_HIST = 14, 18, 15, 10
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka "
+        "WV IV dt t_delta t_cycle T_fill T3_0 T3_end T4_end T5_end t_settle t_draw "
+        "So_sat Kla_min Kla_max Kc_DO tauI_DO tauD_DO EC_min EC_max Kc_EC tauI_EC tauD_EC EC_conc "
+        "act_DO_max act_EC_max biomass_setpoint Qeff settler_area settler_vmax").split()] + [
+        ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
+        ("terminal", C.c_int32), ("auto_reset", C.c_int32)]
+
+
+class Env(C.Structure):
+    _fields_ = [("x", C.c_double * NX), ("t", C.c_double),
+                ("so_m1", C.c_double), ("so_m2", C.c_double), ("sno_m1", C.c_double), ("sno_m2", C.c_double),
+                ("ie_do", C.c_double), ("ie_ec", C.c_double),
+                ("kla_last", C.c_double), ("ec_last", C.c_double), ("ec_prev", C.c_double),
+                ("u_do", C.c_double), ("u_ec", C.c_double),
+                ("kla_hist", C.c_double * KLA_HIST),
+                ("qw", C.c_double), ("ret", C.c_double), ("steps", C.c_double), ("done", C.c_double),
+                ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
+                ("n_rows", C.c_int32), ("n_intervals", C.c_int32)]
+
+
+ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "f8"), ("sno_m1", "f8"),
+                      ("sno_m2", "f8"), ("ie_do", "f8"), ("ie_ec", "f8"), ("kla_last", "f8"), ("ec_last", "f8"),
+                      ("ec_prev", "f8"), ("u_do", "f8"), ("u_ec", "f8"), ("kla_hist", "f8", KLA_HIST),
+                      ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("influent", "f8", NX),
+                      ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4")], align=True)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sbr_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsbr_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        assert _lib.sbro_sizeof_env() == C.sizeof(Env) == ENV_DTYPE.itemsize, "oracle env layout drifted"
+        assert _lib.sbro_sizeof_params() == C.sizeof(Params), "oracle params layout drifted"
+    return _lib
+
+
+def default_params():
+    p = Params()
+    lib().sbro_default_params(C.byref(p))
+    return p
+
+
+def _p(a, t=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+class OracleBatch:
+    """N environments stepped by the C oracle (RK4, fp64, OpenMP over envs)."""
+
+    def __init__(self, n, params=None, nthreads=1, first_env_id=0):
+        self.n, self.nthreads, self.first_env_id = int(n), int(nthreads), int(first_env_id)
+        self.p = params if params is not None else default_params()
+        self.envs = np.zeros(self.n, dtype=ENV_DTYPE)
+
+    def _envp(self):
+        return self.envs.ctypes.data_as(C.POINTER(Env))
+
+    def mix(self, means, stds, scenario, rnd):
+        """influent_mixed [n][14] from tables[8,14,48], scenario [n], rnd [n][48]."""
+        out = np.empty((self.n, NX))
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        stds = np.ascontiguousarray(stds, dtype=np.float64)
+        rnd = np.ascontiguousarray(rnd, dtype=np.float64)
+        for i in range(self.n):
+            s = int(scenario[i])
+            lib().sbro_influent_mix(_p(means[s]), _p(stds[s]), _p(rnd[i]), _p(out[i]))
+        return out
+
+    def normals(self, seed):
+        out = np.empty((self.n, 48))
+        for i in range(self.n):
+            lib().sbro_draw_normals(C.c_uint64(seed), C.c_uint64(self.first_env_id + i), _p(out[i]))
+        return out
+
+    def reset(self, influent):
+        influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64)
+        obs = np.empty((self.n, NOBS))
+        lib().sbro_batch_reset(C.byref(self.p), C.c_int64(self.n), self._envp(), _p(influent), _p(obs),
+                               C.c_int(self.nthreads))
+        return obs
+
+    def step(self, action, want_obs=True):
+        # float64 actions, like the reference; to mirror the product (float32 action tensors) pass
+        # actions.astype(np.float32) - the values are then used exactly
+        action = np.ascontiguousarray(np.broadcast_to(action, (self.n, 2)), dtype=np.float64)
+        obs = np.empty((self.n, NOBS)) if want_obs else None
+        state = np.empty((self.n, NSTATE)) if want_obs else None
+        reward = np.empty(self.n)
+        done = np.empty(self.n, dtype=np.uint8)
+        lib().sbro_batch_step(C.byref(self.p), C.c_int64(self.n), self._envp(), _p(action), _p(obs),
+                              _p(state), _p(reward), _p(done, C.c_uint8), C.c_int(self.nthreads))
+        return obs, state, reward, done
+
+    def rollout(self, n_steps, policy_seed):
+        ret = np.empty(self.n)
+        lib().sbro_batch_rollout(C.byref(self.p), C.c_int64(self.n), self._envp(), C.c_int64(self.first_env_id),
+                                 C.c_int32(n_steps), C.c_uint64(policy_seed), _p(ret), C.c_int(self.nthreads))
+        return ret
+
+    def policy_actions(self, n_steps, policy_seed):
+        """actions [n_steps][n][2] of the on-device random policy, for calls 0..n_steps-1."""
+        out = np.empty((n_steps, self.n, 2), dtype=np.float32)
+        a = (C.c_float * 2)()
+        for s in range(n_steps):
+            for i in range(self.n):
+                lib().sbro_policy_action(C.byref(self.p), C.c_uint64(policy_seed),
+                                         C.c_uint64(self.first_env_id + i), C.c_uint32(s), a)
+                out[s, i] = a[0], a[1]
+        return out
+
+
+def eval_rhs(kind, x, kla, ec, loading=None, params=None):
+    p = params if params is not None else default_params()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(x)
+    dx = np.empty_like(x)
+    kla = np.ascontiguousarray(kla, dtype=np.float64)
+    ec = np.ascontiguousarray(ec, dtype=np.float64)
+    ld = None if loading is None else np.ascontiguousarray(loading, dtype=np.float64)
+    lib().sbro_eval_rhs(C.byref(p), C.c_int(kind), C.c_int64(n), _p(x), _p(kla), _p(ec), _p(ld), _p(dx))
+    return dx
+
+
+def rk4(kind, x, span, n, kla, ec=0.0, loading=None, params=None):
+    p = params if params is not None else default_params()
+    x = np.array(x, dtype=np.float64)
+    ld = None if loading is None else np.ascontiguousarray(loading, dtype=np.float64)
+    lib().sbro_rk4(C.byref(p), C.c_int(kind), _p(x), C.c_double(span), C.c_int(n), C.c_double(kla), C.c_double(ec),
+                   _p(ld))
+    return x

@@ -1,0 +1,418 @@
+"""CPU oracle, layer 1: NumPy/SciPy restatement of the SBROS-v1 path (TEST INFRASTRUCTURE).
+
+Restates - it does not import - the reference's `SbrOS` algorithm
+(/root/reference/gym_SBR/envs/gym_SBR_oneshot.py) for ONE environment, with the same
+integrator the reference uses (SciPy's LSODA through `scipy.integrate.odeint`, an
+un-vendored third-party dependency of the reference: call sites :1647, :1953, :2041,
+:2318-2319, :2587) or, with `integrator="rk4"`, the fixed-step RK4 (10 substeps per control
+interval) that the HIP kernels and the C oracle (oracle/sbr_oracle.c) use.
+
+Pinned by tests/test_oracle_golden.py against tests/golden/*.npz, which were captured from the
+running reference by oracle/gen_golden.py.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product never does.
+
+State vector: 0=V 1=Si 2=Ss 3=Xi 4=Xs 5=Xbh 6=Xba 7=Xp 8=So 9=Sno 10=Snh 11=Snd 12=Xnd 13=Salk
+(gym_SBR_oneshot.py:185-188).
+"""
+import math
+
+import numpy as np
+from scipy.integrate import odeint
+
+from . import sbr_params as P
+
+# stoichiometric coefficients nu[component][process] (gym_SBR_oneshot.py:1689-1725), written with
+# the same expressions so that the values are bit-identical
+_NU = {
+    (2, 1): -1 / P.YH, (5, 1): 1.0, (8, 1): -(1 - P.YH) / P.YH, (10, 1): -P.IXB, (13, 1): -P.IXB / 14,
+    (2, 2): -1 / P.YH, (5, 2): 1.0, (9, 2): -((1 - P.YH) / (2.86 * P.YH)), (10, 2): -P.IXB,
+    (13, 2): (1 - P.YH) / (14 * 2.86 * P.YH) - P.IXB / 14,
+    (6, 3): 1.0, (8, 3): -(4.57 - P.YA) / P.YA, (9, 3): 1 / P.YA, (10, 3): -P.IXB - 1 / P.YA,
+    (13, 3): -P.IXB / 14 - 1 / (7 * P.YA),
+    (4, 4): 1 - P.IXP, (5, 4): -1.0, (7, 4): P.IXP, (12, 4): P.IXB - P.FP * P.IXP,
+    (4, 5): 1 - P.IXP, (6, 5): -1.0, (7, 5): P.IXP, (12, 5): P.IXB - P.FP * P.IXP,
+    (10, 6): 1.0, (11, 6): -1.0, (13, 6): 1 / 14,
+    (2, 7): 1.0, (4, 7): -1.0,
+    (11, 8): 1.0, (12, 8): -1.0,
+}
+# NOTE on naming: the reference's Spar = [Ya, Yh, fp, ixb, ixp] and its nu4_4 = 1 - Spar[4],
+# nu7_4 = Spar[4], nu12_4 = Spar[3] - Spar[2]*Spar[4]  (gym_SBR_oneshot.py:1707-1715).
+
+
+def process_rates(x):
+    """The eight ASM1 process rates, gym_SBR_oneshot.py:1660-1685 (same association order)."""
+    ss, xs, xbh, xba, so, sno, snh, snd, xnd = x[2], x[4], x[5], x[6], x[8], x[9], x[10], x[11], x[12]
+    r1 = P.MUH * (ss / (P.KS + ss)) * (so / (P.KOH + so)) * xbh
+    r2 = P.MUH * (ss / (P.KS + ss)) * (P.KOH / (so + P.KOH)) * (sno / (P.KNO + sno)) * P.ETAG * xbh
+    r3 = P.MUA * (snh / (P.KNH + snh)) * (so / (P.KOA + so)) * xba
+    r4 = P.BH * xbh
+    r5 = P.BA * xba
+    r6 = P.KA * snd * xbh
+    r7 = P.KH * ((xs / xbh) / (P.KX + (xs / xbh))) * (
+        (so / (P.KOH + so)) + P.ETAH * (P.KOH / (so + P.KOH)) * (sno / (P.KNO + sno))) * xbh
+    r8 = (xnd / xs) * r7
+    return r1, r2, r3, r4, r5, r6, r7, r8
+
+
+def conversion(x, kla):
+    """Net conversion rates r[1..13] incl. aeration, gym_SBR_oneshot.py:1731-1755."""
+    rho = (None,) + process_rates(x)
+    n = _NU
+    r = [0.0] * 14
+    r[2] = n[2, 1] * rho[1] + n[2, 2] * rho[2] + n[2, 7] * rho[7]
+    r[4] = n[4, 4] * rho[4] + n[4, 5] * rho[5] + n[4, 7] * rho[7]
+    r[5] = n[5, 1] * rho[1] + n[5, 2] * rho[2] + n[5, 4] * rho[4]
+    r[6] = n[6, 3] * rho[3] + n[6, 5] * rho[5]
+    r[7] = n[7, 4] * rho[4] + n[7, 5] * rho[5]
+    r[8] = n[8, 1] * rho[1] + n[8, 3] * rho[3] + kla * (P.SO_SAT - x[8])
+    r[9] = n[9, 2] * rho[2] + n[9, 3] * rho[3]
+    r[10] = n[10, 1] * rho[1] + n[10, 2] * rho[2] + n[10, 3] * rho[3] + n[10, 6] * rho[6]
+    r[11] = n[11, 6] * rho[6] + n[11, 8] * rho[8]
+    r[12] = n[12, 4] * rho[4] + n[12, 5] * rho[5] + n[12, 8] * rho[8]
+    r[13] = n[13, 1] * rho[1] + n[13, 2] * rho[2] + n[13, 3] * rho[3] + n[13, 6] * rho[6]
+    return r
+
+
+def rhs_reaction(x, t, kla, ec):
+    """reaction_dxdt, gym_SBR_oneshot.py:1658-1787: conversion + carbon dosing/dilution."""
+    r = conversion(x, kla)
+    d = np.zeros(14)
+    d[0] = 0 + ec
+    q = ec / x[0]
+    for i in range(1, 14):
+        d[i] = r[i] + q * ((P.EC_CONC - x[i]) if i == 2 else (-x[i]))
+    return d
+
+
+def rhs_fill(x, t, kla, loading):
+    """filling_dxdt with EC = 0, gym_SBR_oneshot.py:1424-1583.  The path only calls it with EC = 0,
+    where the in-place dilution block :1523-1551 reduces to x[i] = (x[i]*V)/V: the identity
+    mathematically but NOT bitwise (<= 1 ulp).  It is deliberately not restated; the known-answer
+    test bounds the effect (3e-15 relative) and shows that adding it back gives bit equality."""
+    r = conversion(x, kla)
+    d = np.zeros(14)
+    d[0] = loading[0]
+    q = loading[0] / x[0]
+    for i in range(1, 14):
+        d[i] = r[i] + q * (loading[i] - x[i])
+    return d
+
+
+def rhs_fill_reference(x, t, kla, loading):
+    """filling_dxdt exactly as the reference executes it at EC = 0 (gym_SBR_oneshot.py:1424-1583):
+    rates from x, then the in-place block :1523-1551 overwrites x[i] with (x[i]*V)/V - which also
+    mutates the integrator's working vector, as in the reference - then the loading terms.  With this
+    form layer 1 in LSODA mode is BIT-IDENTICAL to the reference (tests/test_oracle_golden.py)."""
+    r = conversion(x, kla)
+    ec = 0.0
+    x[0] = x[0] + ec
+    for i in range(1, 14):
+        x[i] = (x[i] * x[0] + P.EC_CONC * ec) / (x[0] + ec) if i == 2 else x[i] * x[0] / (x[0] + ec)
+    d = np.zeros(14)
+    d[0] = loading[0]
+    for i in range(1, 14):
+        d[i] = r[i] + (loading[0] / x[0]) * (loading[i] - x[i])
+    return d
+
+
+def rhs_idle(x, t, kla):
+    """idle_dxdt, gym_SBR_oneshot.py:2424-2552: conversion only, volume constant."""
+    r = conversion(x, kla)
+    d = np.zeros(14)
+    d[1:] = r[1:]
+    return d
+
+
+def rk4(f, x, t0, t1, n, args):
+    """Classical RK4 with n equal substeps (what the HIP kernels do); f is autonomous here."""
+    h = (t1 - t0) / n
+    x = np.array(x, dtype=np.float64)
+    for _ in range(n):
+        k1 = f(x, 0.0, *args)
+        k2 = f(x + (0.5 * h) * k1, 0.0, *args)
+        k3 = f(x + (0.5 * h) * k2, 0.0, *args)
+        k4 = f(x + h * k3, 0.0, *args)
+        x = x + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    return x
+
+
+def influent_mix(means, stds, rnd):
+    """buffer_tank3.py:68-107 for one scenario: series = mean + std*rnd (one rnd vector shared by
+    all series), flow-weighted means; returns [0.66, Si..Salk].  means/stds: [14,48], last row = q."""
+    series = means + stds * rnd[None, :]
+    q = series[13]
+    sq = sum(q)
+    return np.array([0.66] + [sum(series[j] * q) / sq for j in range(13)])
+
+
+def settle_closed_form(xf, c_t):
+    """Layer concentrations after the settling phase.
+
+    settling_dsXdt (gym_SBR_oneshot.py:2171-2262) has v = max(vmax, exp-exp) == vmax = 474
+    always, hence the linear system dsX0 = c*sX1, dsXi = c*(sX(i+1) - sXi) (i=1..8),
+    dsX9 = -c*sX9 with c = 474/z and all layers starting at Xf.  Exact solution with a = c*T:
+    sX(9-j) = Xf*e^-a*sum_{m<=j} a^m/m!  (j = 0..8),  sX0 = 10*Xf - sum(others).
+    """
+    e = math.exp(-c_t)
+    sx = np.zeros(10)
+    term, partial = 1.0, 0.0
+    for j in range(9):
+        partial += term                  # sum_{m<=j} a^m/m!
+        sx[9 - j] = xf * e * partial
+        term *= c_t / (j + 1)
+    sx[0] = 10.0 * xf - sum(sx[1:])       # sequential, the order oracle/sbr_oracle.c uses
+    return sx
+
+
+class SbrOsRef:
+    """One SBROS-v1 environment, restated.  API mirrors SbrOS: reset() -> (obs_DO, obs_EC),
+    step(a) -> ((obs_DO, obs_EC), state, reward, done, {})."""
+
+    def __init__(self, tables=None, integrator="lsoda", settle="lsoda"):
+        self.tables = tables            # (means[8,14,48], stds[8,14,48]) or None if influent is given
+        self.integrator = integrator
+        self.settle = settle if integrator == "lsoda" else "closed"
+
+    # ------------------------------------------------------------------ integrate one span
+    def _integrate(self, f, x, t0, t1, n_rows, n_sub, args):
+        if self.integrator == "lsoda":
+            grid = np.linspace(t0, t1, n_rows)
+            rows = odeint(f, x, grid, args=args)
+            return rows[-1].copy(), rows
+        return rk4(f, x, t0, t1, n_sub, args), None
+
+    # ------------------------------------------------------------------ reset (:168-438)
+    def reset(self, rnd=None, scenario=P.SCENARIO_DEFAULT, influent=None):
+        if influent is None:
+            means, stds = self.tables
+            influent = influent_mix(means[scenario], stds[scenario], np.asarray(rnd, dtype=np.float64))
+        infl = np.array(influent, dtype=np.float64)
+        self.iv = P.IV_INIT
+        self.qin = P.WV - self.iv
+        infl[0] = self.qin / P.T1_END                       # :287
+        self.influent = infl
+        x0 = np.array(P.X0_INIT, dtype=np.float64)
+        self.u_do, self.u_ec = P.U_DO_INIT, P.U_EC_INIT
+        # controller memories (lists in the reference; only the tails matter)
+        so_hist = [x0[8]]
+        sno_hist = [x0[9]]
+        # Sim_filling :1585-1654 : DO-PID with sp=0 at t_start == 0  => ie = 0, dcv = 0
+        e = 0 - so_hist[-1]
+        ie_do = 0.0
+        kla = P.KC_DO * e + P.KC_DO / P.TAUI_DO * ie_do + P.KC_DO * P.TAUD_DO * 0 + 0
+        if kla > P.KLA_MAX:
+            kla = P.KLA_MAX
+            ie_do = ie_do - e * P.DT
+        if kla < P.KLA_MIN:
+            kla = P.KLA_MIN
+            ie_do = ie_do - e * P.DT
+        ie_ec = 0.0                                          # EC forced to 0, no clamp fires
+        t_end = 0 + P.T_RATIO[0] * 0.5
+        n_rows = int((t_end - 0) / P.DT)
+        # LSODA mode restates the reference bit for bit; RK4 mode uses the clean form the kernels use
+        f_fill = rhs_fill_reference if self.integrator == "lsoda" else rhs_fill
+        x1, rows = self._integrate(f_fill, x0.copy(), 0.0, t_end, n_rows, n_rows, (kla, infl))
+        so_hist.append(x1[8])
+        sno_hist.append(x1[2])                               # :1652 stores Ss into the Sno memory
+        self.x = x1
+        self.t = t_end
+        self.so_m1, self.so_m2 = so_hist[-1], so_hist[-2]
+        self.sno_m1, self.sno_m2 = sno_hist[-1], sno_hist[-2]
+        self.ie_do, self.ie_ec = ie_do, ie_ec
+        # Kla/EC lists are [0, k] replicated (:320-324); keep the last 10 entries
+        reps = n_rows // 2
+        self.kla_hist = ([0.0, kla] * reps)[-10:]
+        self.ec_prev = 0.0
+        self.kla_last, self.ec_last = self.kla_hist[-1], 0.0
+        self.done = False
+        self.n_fill_rows = n_rows
+        self.x_fill_rows = rows
+        # reset observation: volume blend of influent and post-fill state (:346-361)
+        blend = lambda i: (self.qin * infl[i] + x1[i] * self.iv) / (self.qin + self.iv)
+        obs_do = [self.t / P.X1_DO[0]] + [blend(i) / s for i, s in zip(P.OBS_IDX_DO[1:], P.X1_DO[1:])]
+        obs_ec = [self.t / P.X1_EC[0]] + [blend(i) / s for i, s in zip(P.OBS_IDX_EC[1:], P.X1_EC[1:])]
+        return (obs_do + self._xdot(x0, x1, P.XDOT_DO), obs_ec + self._xdot(x0, x1, P.XDOT_EC))
+
+    @staticmethod
+    def _xdot(xa, xb, spec):
+        return [min(1.0, max(-1.0, (xb[i] - xa[i]) / s)) for i, s in spec]
+
+    # ------------------------------------------------------------------ one control interval
+    def _interval(self, aerobic):
+        """Sim_aero_rxn :1877-1963 / Sim_anaero_rxn :1965-2051 + run_*_step :1331-1419."""
+        t0 = self.t
+        t1 = t0 + P.T_DELTA
+        n_rows = int((t1 - t0) / P.DT)                       # 9 or 10, fp-dependent (:1339, :1384)
+        # DO PID (set-point 0 in anoxic intervals; output forced to 0 there but the integral winds)
+        sp_do = self.u_do if aerobic else 0
+        e = sp_do - self.so_m1
+        dcv = (self.so_m1 - self.so_m2) / P.DT
+        self.ie_do = self.ie_do + e * P.DT
+        if aerobic:
+            kla = P.KC_DO * e + P.KC_DO / P.TAUI_DO * self.ie_do + P.KC_DO * P.TAUD_DO * dcv + self.kla_last
+        else:
+            kla = 0
+        if kla > P.KLA_MAX:
+            kla = P.KLA_MAX
+            self.ie_do = self.ie_do - e * P.DT
+        if kla < P.KLA_MIN:
+            kla = P.KLA_MIN
+            self.ie_do = self.ie_do - e * P.DT
+        # NO3 PID -> carbon dosing (error sign reversed; forced to 0 in aerobic intervals)
+        e2 = self.sno_m1 - self.u_ec
+        dcv2 = (self.sno_m1 - self.sno_m2) / P.DT
+        self.ie_ec = self.ie_ec + e2 * P.DT
+        if aerobic:
+            ec = 0
+        else:
+            ec = P.KC_EC * e2 + P.KC_EC / P.TAUI_EC * self.ie_ec + P.KC_EC * P.TAUD_EC * dcv2 + self.ec_last
+        if ec < P.EC_MIN:
+            ec = P.EC_MIN
+            self.ie_ec = self.ie_ec - e2 * P.DT
+        elif ec > P.EC_MAX:
+            ec = P.EC_MAX
+            self.ie_ec = self.ie_ec - e2 * P.DT
+        x0 = self.x
+        x1, rows = self._integrate(rhs_reaction, x0, t0, t1, n_rows, 10, (float(kla), float(ec)))
+        # bookkeeping of the lists the reward looks at
+        self.kla_hist = (self.kla_hist + [float(kla)])[-10:]
+        self.ec_prev, self.ec_last = self.ec_last, float(ec)
+        self.kla_last = float(kla)
+        self.so_m2, self.so_m1 = self.so_m1, x1[8]
+        self.sno_m2, self.sno_m1 = self.sno_m1, x1[9]
+        self.x_start, self.x, self.t = x0, x1, t1
+        self.last = dict(t0=t0, t1=t1, n_rows=n_rows, kla=float(kla), ec=float(ec), rows=rows,
+                         aerobic=aerobic, x_start=x0, x_end=x1)
+        self.intervals.append(self.last)
+
+    # ------------------------------------------------------------------ reward (module_reward_EQIOCI.py:4-115)
+    def _reward(self):
+        x = self.x
+        n = self.last["n_rows"]
+        xi, xs, xbh, xba, xp = x[3], x[4], x[5], x[6], x[7]
+        snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi)
+        ss_ = 0.75 * (xs + xi + xbh + xba + xp)
+        bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * (xbh + xba))
+        cod = x[2] + x[1] + xs + xi + xbh + xba + xp
+        eqi = (2 * ss_ + 1 * cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1 / 1000) * 0.66
+        eqi2 = eqi / 10
+        td = 0.002 / 24
+        span = self.last["t1"] - self.last["t0"]
+        # Kla got ONE append per interval: Kla[-n:-1] = the n-1 values before the current one
+        ae_dt = 1.32 * sum(self.kla_hist[-n:-1]) * td
+        ae = 8 / (span * 1.8 * 1000) * ae_dt
+        ae_max = 1.32 * (240 * 11) * td * (8 / ((td * 11) * 1.8 * 1000))
+        # EC got n-1 appends per interval: EC[-n:-1] = last value of the previous interval + (n-2) current
+        ec_sum = sum([self.ec_prev] + [self.ec_last] * (n - 2))
+        ec_oci = P.EC_CONC * ec_sum * td / (span * 1000)
+        ec_max = P.EC_CONC * (0.0005 * 11) * td / ((td * 11) * 1000)
+        oci = ae + ec_oci
+        reward = (1 - (eqi2 ** 2 + oci ** 2)) / 473
+        self.reward_parts = (eqi2, ae / ae_max + ec_oci / ec_max, ae / ae_max, ec_oci / ec_max)
+        return reward
+
+    def _obs(self, t_obs, x, x_from):
+        state = np.array([t_obs] + list(x)) / np.array(P.X1_STATE, dtype=np.float64)
+        obs_do = [t_obs / P.X1_DO[0]] + [x[i] / s for i, s in zip(P.OBS_IDX_DO[1:], P.X1_DO[1:])]
+        obs_ec = [t_obs / P.X1_EC[0]] + [x[i] / s for i, s in zip(P.OBS_IDX_EC[1:], P.X1_EC[1:])]
+        return (obs_do + self._xdot(x_from, x, P.XDOT_DO), obs_ec + self._xdot(x_from, x, P.XDOT_EC)), state
+
+    # ------------------------------------------------------------------ step (:843-1273)
+    def step(self, action):
+        self.intervals = []
+        a_do = min(max(float(action[0]), 0.0), P.ACT_DO_MAX)
+        a_ec = min(max(float(action[1]), 0.0), P.ACT_EC_MAX)
+        # four sequential tests on the running time: a call that crosses a phase boundary runs
+        # a second interval (3 times per episode)
+        if self.t < P.T3_0:
+            self.u_ec, self.u_do = a_ec, 0
+            self._interval(aerobic=False)
+        if (self.t >= P.T3_0) and (self.t <= P.T3_END):
+            self.u_do, self.u_ec = a_do, 0
+            self._interval(aerobic=True)
+        if (self.t > P.T3_END) and (self.t <= P.T4_END):
+            self.u_ec, self.u_do = a_ec, 0
+            self._interval(aerobic=False)
+        if self.t > P.T4_END:
+            self.u_do, self.u_ec = a_do, 0
+            self._interval(aerobic=True)
+        reward = self._reward()
+        obs, state = self._obs(self.t, self.x, self.x_start)
+        done = False
+        if self.t >= P.T5_END:
+            done = True
+            x_pre = self.x
+            x_drawn = self._settle_draw(x_pre, self.t)
+            x_idle = self._idle(x_drawn)
+            obs, state = self._obs(P.T_CYCLE, x_idle, x_pre)
+            self.x_after_draw, self.x_after_idle = x_drawn, x_idle
+            self.done = True
+        return obs, state, reward, done, {}
+
+    # ------------------------------------------------------------------ settle + draw (:2264-2420)
+    def _settle_draw(self, x, t):
+        xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7])
+        vs = x[0]
+        z = vs / P.SETTLER_AREA
+        t_set = P.T_RATIO[5] * P.T_CYCLE
+        if self.settle == "lsoda":
+            def f(sx, tt):
+                j = P.SETTLER_VMAX * sx                       # v == vmax always (:2226-2235)
+                d = np.empty(10)
+                d[0] = j[1] / z
+                d[1:9] = (j[2:10] - j[1:9]) / z
+                d[9] = (0 - j[9]) / z
+                return d
+            grid = np.linspace(t, t + t_set, int(t_set / P.T_DELTA))
+            sx = odeint(f, [xf] * 10, grid)[-1]
+        else:
+            sx = settle_closed_form(xf, P.SETTLER_VMAX / z * t_set)
+        self.t_after_draw = (t + t_set) + P.T_RATIO[6] * P.T_CYCLE
+        layer_v = vs / 10
+        resid_v = vs - P.QEFF
+        m = int(math.ceil(round(P.QEFF / layer_v)))
+        self.sx_eff = sum(sx[-m:-1] * layer_v)                # drops the last layer (:2344)
+        w = layer_v * sx[0:10 - m]
+        resid_sx = sx[0:10 - m].copy()
+        waste = sum(w) - P.BIOMASS_SETPOINT * resid_v
+        qw = float("nan")
+        for i in range(10 - m):
+            rest = waste - w[i]
+            if rest > 0:
+                waste = rest
+                resid_sx[i] = 0
+                w[i] = 0
+                resid_v -= layer_v
+            else:
+                qw = waste / (resid_sx[i] - P.BIOMASS_SETPOINT)
+                w[i] = w[i] - qw * resid_sx[i]
+                resid_v -= qw
+                resid_sx[i] = w[i] / (layer_v - qw)
+                break
+        self.qw, self.waste_w = qw, waste
+        sx2 = sum(w) / resid_v
+        xn = np.array(x, dtype=np.float64)
+        xn[0] = resid_v
+        for i in (3, 4, 5, 6, 7):
+            xn[i] = x[i] * (1 / 0.75) * sx2 / xf
+        return xn
+
+    # ------------------------------------------------------------------ idle (:2554-2597)
+    def _idle(self, x):
+        t0 = self.t_after_draw
+        t1 = P.T_CYCLE
+        # So memory was extended with the (constant) settle/draw rows: So[-1] == So[-2] == x[8]
+        e = self.u_do - x[8]
+        self.ie_do = self.ie_do + e * P.DT
+        kla = P.KC_DO * e + P.KC_DO / P.TAUI_DO * self.ie_do + P.KC_DO * P.TAUD_DO * 0.0 + self.kla_last
+        if kla > P.KLA_MAX:
+            kla = P.KLA_MAX
+            self.ie_do = self.ie_do - e * P.DT
+        if kla < P.KLA_MIN:
+            kla = P.KLA_MIN
+            self.ie_do = self.ie_do - e * P.DT
+        self.kla_idle = float(kla)
+        n_rows = int((t1 - t0) / P.DT)
+        x1, _ = self._integrate(rhs_idle, x, t0, t1, n_rows, n_rows, (float(kla),))
+        self.n_idle_rows = n_rows
+        return x1

@@ -1,0 +1,293 @@
+"""Pins the CPU oracle (oracle/) against the golden vectors captured from the reference.
+
+What is asserted, and why it is worded this way (measured numbers in DESIGN.md, section Parity):
+
+* Layer 1 (oracle/sbr_ref.py, same LSODA as the reference) reproduces every golden episode -
+  intervals per call, done, Kla, EC, rewards, observations, terminal phases - to ~1e-11 relative.
+* Layer 2 (oracle/sbr_oracle.c, fixed-step RK4 = what the HIP kernels compute) is bit-identical to
+  layer 1 run in RK4 mode.
+* RK4 vs the reference, OPEN loop: from the golden start state of each of the 466 intervals of every
+  episode, with the golden Kla/EC, the end state is inside the gate (|d| <= 1e-5|ref| + 1e-5 scale).
+* RK4 vs the reference, CLOSED loop (chained over the whole episode): inside the gate for four of
+  the six episodes.  In `random_b` and `zeros` the golden trajectory ITSELF is 2.6x / 1.35x outside
+  the gate (in Ss only) relative to a tight-tolerance (1e-12) solve of the same closed loop: the
+  reference's default LSODA tolerance (1.5e-8) is amplified by the NO3-PID -> carbon-dosing loop
+  (dEC = 100 dSno, dSs ~ 3030 dEC per interval).  No integrator other than the bit-identical LSODA
+  can follow it there, so for those two the test asserts RK4 against the tight solve instead and
+  asserts the golden exceedance, so that it stays visible rather than being tolerated silently.
+"""
+import numpy as np
+import pytest
+from conftest import EPISODES, gate, golden
+
+from oracle import sbr_oracle as O
+from oracle import sbr_params as P
+from oracle import sbr_ref as R
+
+CLOSED_LOOP_OK = ["const_2_5", "random_a", "max", "det_influent"]
+CLOSED_LOOP_REFERENCE_NOISE = ["random_b", "zeros"]
+
+
+def test_constants_match_reference():
+    c = golden("constants")
+    for key, val in [("T1_end", P.T1_END), ("T3_0", P.T3_0), ("T3_end", P.T3_END), ("T4_end", P.T4_END),
+                     ("T5_end", P.T5_END), ("So_sat", P.SO_SAT), ("dt", P.DT), ("t_delta", P.T_DELTA),
+                     ("EC_conc", P.EC_CONC)]:
+        assert float(c[key]) == val, key
+    assert [p[2] for p in P.phase_times()] == c["lens"].tolist()
+    p = O.default_params()
+    for key, val in [("T1_end", p.T_fill), ("T3_0", p.T3_0), ("T3_end", p.T3_end), ("T4_end", p.T4_end),
+                     ("T5_end", p.T5_end), ("So_sat", p.So_sat), ("dt", p.dt), ("t_delta", p.t_delta)]:
+        assert float(c[key]) == val, key
+
+
+def test_rhs_known_answers():
+    k = golden("rhs_kat")
+    n = len(k["X"])
+    zero = np.zeros(n)
+    # reaction and idle right-hand sides: bit-exact in both oracle layers
+    assert np.array_equal(O.eval_rhs(0, k["X"], k["kla"], k["ec"]), k["d_reaction"])
+    assert np.array_equal(O.eval_rhs(2, k["X"], k["kla"], zero), k["d_idle"])
+    for i in range(n):
+        assert np.array_equal(R.rhs_reaction(k["X"][i], 0.0, k["kla"][i], k["ec"][i]), k["d_reaction"][i])
+        assert np.array_equal(R.rhs_idle(k["X"][i], 0.0, k["kla"][i]), k["d_idle"][i])
+    # filling: the reference's in-place dilution block (gym_SBR_oneshot.py:1523-1551) is (x*V)/V at
+    # EC = 0 - not a bitwise no-op.  Not restated => <= 1 ulp of the largest term, i.e. 1e-14 relative.
+    ref = k["d_filling"]
+    tol = 1e-14 * np.abs(ref).max(axis=1, keepdims=True)
+    c_fill = O.eval_rhs(1, k["X"], k["kla"], zero, k["loading"])
+    assert np.all(np.abs(c_fill - ref) <= tol)
+    # ... and that really is the whole difference: with the round trip put back it is bit-exact
+    for i in range(n):
+        x, ld = k["X"][i], k["loading"][i]
+        r = R.conversion(x, k["kla"][i])
+        y = np.array([x[0]] + [x[j] * x[0] / (x[0] + 0.0) for j in range(1, 14)])
+        d = np.array([ld[0]] + [r[j] + (ld[0] / x[0]) * (ld[j] - y[j]) for j in range(1, 14)])
+        assert np.array_equal(d, ref[i])
+        assert np.array_equal(R.rhs_fill(x, 0.0, k["kla"][i], ld), c_fill[i])       # layers agree bitwise
+    # anchor from SURVEY.md section 8c: RHS at x0_init, Kla = 100, EC = 0
+    d = k["d_reaction"][12]
+    assert abs(d[2] + 1.3417542) < 1e-6 and abs(d[5] + 228.94854228) < 1e-6
+
+
+def test_influent_mix_exact(tables):
+    means, stds = tables
+    ik = golden("influent_kat")
+    b = O.OracleBatch(len(ik["scenario"]))
+    assert np.array_equal(b.mix(means, stds, ik["scenario"], ik["rnd"]), ik["mixed"])
+    for s, r, m in zip(ik["scenario"], ik["rnd"], ik["mixed"]):
+        assert np.array_equal(R.influent_mix(means[s], stds[s], r), m)
+
+
+def test_interval_row_count_is_9_or_10():
+    """SURVEY.md section 8a assumed 9 rows always; the reference produces 9 or 10 (fp rounding of
+    (t+t_delta)-t), which changes how far back the reward looks."""
+    e = golden("sbros_const_2_5")
+    n = e["iv_n_rows"]
+    assert set(n.tolist()) == {9, 10} and (n == 10).sum() == 266
+    calc = [int(((t + P.T_DELTA) - t) / P.DT) for t in e["iv_t_start"]]
+    assert calc == n.tolist()
+
+
+@pytest.mark.parametrize("name", EPISODES)
+def test_layer1_lsoda_restatement_is_bit_identical_to_reference(name, tables):
+    """Same LSODA, restated algorithm: every state, reward, observation and controller output of every
+    call equals the reference's BIT FOR BIT (no tolerance), terminal phases included."""
+    e = golden("sbros_" + name)
+    env = R.SbrOsRef(tables)
+    obs = env.reset(rnd=e["rnd"])
+    assert env.n_fill_rows == int(e["n_fill_rows"]) == 252
+    assert np.array_equal(env.influent, e["influent_mixed"])
+    assert np.array_equal(env.x, e["x_postfill"])
+    assert np.array_equal(obs[0], e["reset_obs_DO"]) and np.array_equal(obs[1], e["reset_obs_EC"])
+    assert np.array_equal(env.kla_hist[-9:], e["reset_Kla_tail"])
+    assert env.ie_do == float(e["reset_ie_DO"]) and env.ie_ec == float(e["reset_ie_EC"])
+    rewards = []
+    for k in range(int(e["n_calls"])):
+        obs, state, r, done, _ = env.step(e["actions"][k])
+        assert done == bool(e["step_done"][k]) and len(env.intervals) == e["step_n_intervals"][k]
+        assert env.last["n_rows"] == e["iv_n_rows"][np.where(e["iv_call"] == k)[0][-1]]
+        assert np.array_equal(env.x, e["step_x_end"][k]), k
+        assert env.kla_last == e["step_Kla"][k] and env.ec_last == e["step_EC"][k]
+        assert env.ie_do == e["step_ie_DO"][k] or done      # the idle phase updates ie_DO on the done call
+        assert env.ie_ec == e["step_ie_EC"][k]
+        assert r == e["step_reward"][k]
+        assert np.array_equal(obs[0], e["step_obs_DO"][k]) and np.array_equal(obs[1], e["step_obs_EC"][k])
+        assert np.array_equal(state, e["step_state"][k])
+        rewards.append(r)
+    assert float(np.sum(rewards)) == float(e["episode_return"])
+    assert env.qw == float(e["term_Qw"])
+    assert np.array_equal(env.x_after_draw, e["term_x_after_draw"])
+    assert np.array_equal(env.x_after_idle, e["term_x_after_idle"])
+    assert env.kla_idle == float(e["term_Kla_idle"]) and env.n_idle_rows == int(e["term_n_idle_rows"])
+
+
+def test_closed_loop_sensitivity_is_why_two_episodes_leave_the_gate(tables):
+    """Measured, not assumed: the SAME code (layer 1, LSODA) restarted from a post-fill state that
+    differs by 1 ulp in Sno drifts by < 1e-7 of the gate in `const_2_5` but ~1e3 times more in `zeros`
+    (amplification ~1e7 from the NO3-PID -> dosing loop).  LSODA's default local error (1.5e-8) times
+    that amplification is what puts the reference's own `zeros`/`random_b` trajectories outside 1e-5."""
+    drift = {}
+    for name in ("const_2_5", "zeros"):
+        e = golden("sbros_" + name)
+        runs = []
+        for kick in (False, True):
+            env = R.SbrOsRef(tables)
+            env.reset(rnd=e["rnd"])
+            if kick:
+                env.x = env.x.copy()
+                env.x[9] = np.nextafter(env.x[9], np.inf)
+            xs = []
+            for k in range(int(e["n_calls"]) - 1):
+                env.step(e["actions"][k])
+                xs.append(env.x.copy())
+            runs.append(np.array(xs))
+        drift[name] = gate(runs[1], runs[0]).max()
+    assert drift["const_2_5"] < 1e-7
+    assert drift["zeros"] > 100 * drift["const_2_5"]
+
+
+@pytest.mark.parametrize("name", EPISODES)
+def test_pid_known_answers_open_loop(name, tables):
+    """Both PIDs + phase logic, open loop: controller memory and plant state of call k-1 are injected
+    from the fixture, one step() is run, and Kla, EC and both integrals must equal the reference's
+    values of call k to rounding (they are computed before the integration, so no integrator noise).
+    Covers anti-windup on both clamps, the integrators that wind while their actuator is forced to 0,
+    the previous-Kla bias and the phase-boundary double steps."""
+    e = golden("sbros_" + name)
+    n = int(e["n_calls"])
+    py = R.SbrOsRef(tables, integrator="rk4")
+    py.reset(rnd=e["rnd"])
+    b = O.OracleBatch(1)
+    b.reset(e["influent_mixed"][None])
+    checked = clamped_hi = clamped_lo = doubles = 0
+    for k in range(1, n):
+        ivs = np.where(e["iv_call"] == k)[0]
+        j = k - 1
+        # EC of the interval before call k's first interval, and the Kla history, from the interval log
+        i0 = ivs[0]
+        py.t, py.x = float(e["step_t"][j]), e["step_x_end"][j].copy()
+        py.so_m1, py.so_m2 = float(e["step_So_m1"][j]), float(e["step_So_m2"][j])
+        py.sno_m1, py.sno_m2 = float(e["step_Sno_m1"][j]), float(e["step_Sno_m2"][j])
+        py.ie_do, py.ie_ec = float(e["step_ie_DO"][j]), float(e["step_ie_EC"][j])
+        py.kla_last, py.ec_last = float(e["step_Kla"][j]), float(e["step_EC"][j])
+        hist = ([0.0] * 10 + e["iv_Kla"][:i0].tolist())[-10:]
+        py.kla_hist = hist
+        py.ec_prev = float(e["iv_EC"][i0 - 2]) if i0 >= 2 else 0.0
+        env = b.envs[0]
+        env["t"], env["x"] = py.t, py.x
+        env["so_m1"], env["so_m2"], env["sno_m1"], env["sno_m2"] = py.so_m1, py.so_m2, py.sno_m1, py.sno_m2
+        env["ie_do"], env["ie_ec"], env["kla_last"], env["ec_last"] = py.ie_do, py.ie_ec, py.kla_last, py.ec_last
+        env["kla_hist"], env["ec_prev"], env["done"] = hist, py.ec_prev, 0.0
+        a = e["actions"][k]
+        py.step(a)
+        b.step(a[None])
+        first = py.intervals[0]
+        assert len(py.intervals) == len(ivs) == b.envs["n_intervals"][0]
+        # first interval of the call: controller outputs depend only on injected memory
+        for got_kla, got_ec in ((first["kla"], first["ec"]),):
+            assert abs(got_kla - e["iv_Kla"][i0]) <= 1e-13 * max(1.0, abs(e["iv_Kla"][i0]))
+            assert abs(got_ec - e["iv_EC"][i0]) <= 1e-13 * 5e-4
+        if len(ivs) == 1:
+            for got, ref in ((py.ie_do, e["step_ie_DO"][k]), (py.ie_ec, e["step_ie_EC"][k]),
+                             (b.envs["ie_do"][0], e["step_ie_DO"][k]), (b.envs["ie_ec"][0], e["step_ie_EC"][k]),
+                             (b.envs["kla_last"][0], e["step_Kla"][k])):
+                assert abs(got - ref) <= 1e-13 * max(1e-3, abs(ref))
+            assert abs(b.envs["ec_last"][0] - e["step_EC"][k]) <= 1e-13 * 5e-4
+        else:
+            doubles += 1
+        clamped_hi += int(e["iv_Kla"][i0] == 240.0) + int(e["iv_EC"][i0] == 5e-4)
+        clamped_lo += int(e["iv_kind"][i0] == 1 and e["iv_Kla"][i0] == 0.0)
+        checked += 1
+    assert checked == n - 1 and doubles == 3
+    if name in ("const_2_5", "max"):
+        assert clamped_hi > 0                      # the upper clamps (with anti-windup) are exercised
+
+
+@pytest.mark.parametrize("name", EPISODES)
+def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(name, tables):
+    means, stds = tables
+    e = golden("sbros_" + name)
+    b = O.OracleBatch(1)
+    cobs = b.reset(b.mix(means, stds, [6], e["rnd"][None]))
+    py = R.SbrOsRef(tables, integrator="rk4")
+    pobs = py.reset(rnd=e["rnd"])
+    assert np.array_equal(cobs[0], np.r_[pobs[0], pobs[1]]) and np.array_equal(b.envs["x"][0], py.x)
+    n = int(e["n_calls"])
+    for k in range(n):
+        o, s, r, d = b.step(e["actions"][k][None])
+        po, ps, pr, pd, _ = py.step(e["actions"][k])
+        assert np.array_equal(o[0], np.r_[po[0], po[1]]) and np.array_equal(s[0], ps)
+        assert abs(r[0] - pr) <= 4e-18 and bool(d[0]) == pd
+        if k < n - 1:                      # on the done call the C env holds the post-idle state
+            assert np.array_equal(b.envs["x"][0], py.x)
+    assert np.array_equal(b.envs["x"][0], py.x_after_idle)
+    assert b.envs["qw"][0] == py.qw
+
+
+@pytest.mark.parametrize("name", EPISODES)
+def test_rk4_open_loop_every_interval_inside_gate(name):
+    e = golden("sbros_" + name)
+    worst = 0.0
+    for i in range(len(e["iv_kind"])):
+        span = e["iv_t_end"][i] - e["iv_t_start"][i]
+        x1 = O.rk4(0, e["iv_x_start"][i], span, 10, e["iv_Kla"][i], e["iv_EC"][i])
+        worst = max(worst, gate(x1, e["iv_x_end"][i]).max())
+    assert worst <= 1.0, worst          # measured worst case: 0.24 (So, first aerobic interval)
+
+
+def _c_episode(e, tables):
+    means, stds = tables
+    b = O.OracleBatch(1)
+    b.reset(b.mix(means, stds, [6], e["rnd"][None]))
+    xs = []
+    for k in range(int(e["n_calls"])):
+        b.step(e["actions"][k][None])
+        xs.append(b.envs["x"][0].copy())
+    return np.array(xs), b
+
+
+@pytest.mark.parametrize("name", CLOSED_LOOP_OK)
+def test_rk4_closed_loop_inside_gate_of_reference(name, tables):
+    e = golden("sbros_" + name)
+    xs, b = _c_episode(e, tables)
+    n = int(e["n_calls"])
+    assert gate(xs[:n - 1], e["step_x_end"][:n - 1]).max() <= 1.0
+    assert gate(xs[n - 1], e["term_x_after_idle"]).max() <= 1.0
+    assert abs(b.envs["ret"][0] - float(e["episode_return"])) < 1e-5 * abs(float(e["episode_return"]))
+    assert abs(b.envs["qw"][0] / float(e["term_Qw"]) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("name", CLOSED_LOOP_REFERENCE_NOISE)
+def test_rk4_closed_loop_where_reference_noise_exceeds_gate(name, tables, monkeypatch):
+    """See the module docstring: here the golden trajectory is not reproducible to 1e-5 by anything
+    but the identical LSODA run.  RK4 must be inside the gate of the tight solve; the golden
+    exceedance is asserted (not hidden), in Ss only."""
+    from scipy.integrate import odeint as _ode
+    e = golden("sbros_" + name)
+    n = int(e["n_calls"])
+    monkeypatch.setattr(R, "odeint", lambda f, x, g, args=(): _ode(f, x, g, args=args, rtol=1e-12, atol=1e-12))
+    tight_env = R.SbrOsRef(tables)
+    tight_env.reset(rnd=e["rnd"])
+    tight = []
+    for k in range(n):
+        tight_env.step(e["actions"][k])
+        tight.append(tight_env.x.copy())
+    tight = np.array(tight)
+    xs, _ = _c_episode(e, tables)
+    assert gate(xs[:n - 1], tight[:n - 1]).max() <= 1.0              # RK4 follows the true closed loop
+    g_gold = gate(e["step_x_end"][:n - 1], tight[:n - 1])
+    g_rk4 = gate(xs[:n - 1], e["step_x_end"][:n - 1])
+    assert 1.0 < g_gold.max() < 3.0                                   # the reference's own noise
+    assert g_gold.max(0).argmax() == 2 and g_rk4.max(0).argmax() == 2  # component Ss
+    others = [i for i in range(14) if i != 2]
+    assert g_rk4[:, others].max() <= 1.0                              # every other component is inside
+    assert abs(g_rk4.max() / g_gold.max() - 1) < 0.05                 # the gap IS the reference's noise
+
+
+def test_philox_normals_are_standard():
+    b = O.OracleBatch(256)
+    z = b.normals(seed=0)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03 and np.isfinite(z).all()
+    assert not np.array_equal(z[0], z[1])
+    assert np.array_equal(O.OracleBatch(1, first_env_id=5).normals(0)[0], z[5])   # keyed by GLOBAL env id
