@@ -1,0 +1,23 @@
+"""gym_sbr2_amd - MI355X-native batched SBR environment (hot path of SungKu/gym-SBR2: SBROS-v1).
+
+Importing this package never touches the GPU.  `SbrOSVec` / `SbrOS` need a gfx950 device and
+libsbr_amd.so (built in-tree by `__graft_entry__.build()`); there is no CPU fallback.
+(The directory is `gym_sbr2_amd` because `gym-sbr2_amd` is not an importable Python name.)
+"""
+from . import _capi  # noqa: F401
+from .registration import make, register_with_gym, registered_ids  # noqa: F401
+
+__version__ = "0.1.0"
+
+
+def __getattr__(name):          # torch is imported only when the env classes are asked for
+    if name == "SbrOSVec":
+        from .vec_env import SbrOSVec
+        return SbrOSVec
+    if name == "SbrOS":
+        from .envs import SbrOS
+        return SbrOS
+    if name == "ShardedSbrOS":
+        from .sharding import ShardedSbrOS
+        return ShardedSbrOS
+    raise AttributeError(name)

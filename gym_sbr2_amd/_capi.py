@@ -1,0 +1,97 @@
+"""ctypes binding of libsbr_amd.so (include/sbr_amd.h).  Plumbing only: no numerics live here.
+
+The library is HIP-only.  Loading works on a machine without a GPU (so the symbol table can be
+checked there), but sbr_create fails loudly - there is no CPU fallback anywhere in the product.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 26, 10
+NSCEN, NSERIES, NSAMP = 8, 14, 48
+# rows of the ctrl block (enum in sbr_amd.h)
+C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST, C_EC_PREV, C_U_DO, C_U_EC = range(11)
+C_KLA_HIST0 = 11
+C_KLA_LAST = C_KLA_HIST0 + KLA_HIST - 1
+C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
+                                              C_KLA_LAST + 5)
+ST_NEGATIVE, ST_NEAR_POLE, ST_NONFINITE = 1, 2, 4     # SBR_ST_* bits of the status row
+
+_DBL = ("Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka "
+        "WV IV dt t_delta t_cycle T_fill T3_0 T3_end T4_end T5_end t_settle t_draw "
+        "So_sat Kla_min Kla_max Kc_DO tauI_DO tauD_DO EC_min EC_max Kc_EC tauI_EC tauD_EC EC_conc "
+        "act_DO_max act_EC_max biomass_setpoint Qeff settler_area settler_vmax").split()
+
+
+class SbrConfig(C.Structure):
+    _fields_ = [(n, C.c_double) for n in _DBL] + [
+        ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
+        ("terminal", C.c_int32), ("act_f64", C.c_int32)]
+
+
+class SbrError(RuntimeError):
+    pass
+
+
+# every symbol include/sbr_amd.h declares: name -> (restype, argtypes)
+_VP, _I64, _U64, _I32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32
+SYMBOLS = {
+    "sbr_version": (C.c_char_p, []),
+    "sbr_default_config": (C.c_int, [C.POINTER(SbrConfig)]),
+    "sbr_device_count": (C.c_int, []),
+    "sbr_create": (C.c_int, [_I64, C.c_int, _I64, C.POINTER(SbrConfig), C.POINTER(_VP)]),
+    "sbr_destroy": (C.c_int, [_VP]),
+    "sbr_last_error": (C.c_char_p, [_VP]),
+    "sbr_num_envs": (_I64, [_VP]),
+    "sbr_set_influent_tables": (C.c_int, [_VP, _VP, _VP]),
+    "sbr_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_rollout": (C.c_int, [_VP, _I32, _U64, _VP, _VP, _VP]),
+    "sbr_reduce_stats": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
+    "sbr_get_state": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "sbr_set_state": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "sbr_get_influent": (C.c_int, [_VP, _VP, _VP]),
+    "sbr_eval_rhs": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_draw_normals": (C.c_int, [_VP, _U64, _VP, _VP]),
+    "sbr_timer_start": (C.c_int, [_VP, _VP]),
+    "sbr_timer_stop": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """dlopen libsbr_amd.so.  Raises if it is missing and cannot be built: the product has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path) or (_build.is_stale() and build_if_missing):
+        if not build_if_missing:
+            raise SbrError("libsbr_amd.so is missing (%s); run python -c 'import __graft_entry__ as g; g.build()'" % path)
+        _build.build_library()
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def default_config():
+    cfg = SbrConfig()
+    rc = load().sbr_default_config(C.byref(cfg))
+    if rc != 0:
+        raise SbrError("sbr_default_config failed: %d" % rc)
+    return cfg
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().sbr_last_error(handle)
+        raise SbrError("libsbr_amd error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,578 @@
+// sbr_amd.hip - kernels + C ABI of libsbr_amd.so (gfx950).  See include/sbr_amd.h for the contract.
+//
+// Kernels (all one-lane-per-env over SoA float64 state, 64-thread workgroups = one wavefront, so a
+// launch of N envs is N/64 independent waves that the dispatcher spreads over the 1024 SIMDs):
+//   k_reset    influent mix (tables in LDS) + fill phase (252 RK4 substeps) + controller init + obs
+//   k_step     one SbrOS.step(): phase logic, 2 PIDs, 10 RK4 substeps (x2 at phase boundaries), reward,
+//              obs/state, and the terminal phases on the last call of an episode
+//   k_rollout  n_steps fused step()s with an on-device Philox policy, plant state stays in VGPRs
+//   k_stats    wavefront (DPP) reductions of a per-env vector -> {sum,min,max,count}
+//   k_rhs, k_normals  known-answer helpers for the parity tests
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sbr_device.h"
+
+#define SBR_BLOCK 64
+static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB
+
+// ------------------------------------------------------------------------------------------- state I/O
+struct SbrBuf {
+    double* x;      // [14][N]
+    double* ctrl;   // [SBR_NCTRL][N]
+    double* infl;   // [14][N]
+    int64_t n;
+    int64_t first_env_id;
+};
+
+SBR_DEV void load_x(const SbrBuf& b, int64_t i, double (&x)[SBR_NX]) {
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) x[j] = b.x[(int64_t)j * b.n + i];
+}
+SBR_DEV void store_x(const SbrBuf& b, int64_t i, const double (&x)[SBR_NX]) {
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) b.x[(int64_t)j * b.n + i] = x[j];
+}
+#define CTRL(f) b.ctrl[(int64_t)(f) * b.n + i]
+SBR_DEV void load_ctl(const SbrBuf& b, int64_t i, SbrCtl& c) {
+    c.t = CTRL(SBR_C_T); c.so_m1 = CTRL(SBR_C_SO_M1); c.so_m2 = CTRL(SBR_C_SO_M2);
+    c.sno_m1 = CTRL(SBR_C_SNO_M1); c.sno_m2 = CTRL(SBR_C_SNO_M2);
+    c.ie_do = CTRL(SBR_C_IE_DO); c.ie_ec = CTRL(SBR_C_IE_EC);
+    c.ec_last = CTRL(SBR_C_EC_LAST); c.ec_prev = CTRL(SBR_C_EC_PREV);
+    c.u_do = CTRL(SBR_C_U_DO); c.u_ec = CTRL(SBR_C_U_EC);
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) c.kh[j] = CTRL(SBR_C_KLA_HIST0 + j);
+    c.qw = CTRL(SBR_C_QW); c.ret = CTRL(SBR_C_RETURN); c.steps = CTRL(SBR_C_STEPS); c.done = CTRL(SBR_C_DONE);
+    c.status = CTRL(SBR_C_STATUS);
+    c.span = 0.0; c.rows = 9;
+}
+SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c) {
+    CTRL(SBR_C_T) = c.t; CTRL(SBR_C_SO_M1) = c.so_m1; CTRL(SBR_C_SO_M2) = c.so_m2;
+    CTRL(SBR_C_SNO_M1) = c.sno_m1; CTRL(SBR_C_SNO_M2) = c.sno_m2;
+    CTRL(SBR_C_IE_DO) = c.ie_do; CTRL(SBR_C_IE_EC) = c.ie_ec;
+    CTRL(SBR_C_EC_LAST) = c.ec_last; CTRL(SBR_C_EC_PREV) = c.ec_prev;
+    CTRL(SBR_C_U_DO) = c.u_do; CTRL(SBR_C_U_EC) = c.u_ec;
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(SBR_C_KLA_HIST0 + j) = c.kh[j];
+    CTRL(SBR_C_QW) = c.qw; CTRL(SBR_C_RETURN) = c.ret; CTRL(SBR_C_STEPS) = c.steps; CTRL(SBR_C_DONE) = c.done;
+    CTRL(SBR_C_STATUS) = c.status;
+}
+#undef CTRL
+
+// ------------------------------------------------------------------------------------------- reset
+// SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
+// workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
+template <typename OutT>
+__global__ __launch_bounds__(SBR_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
+                                                    uint64_t seed, const int32_t* __restrict__ scenario,
+                                                    const double* __restrict__ rnd, const double* __restrict__ influent,
+                                                    const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][14][48]
+    const bool need_tables = (influent == nullptr);
+    if (need_tables) {
+        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_BLOCK) lds[k] = tables[k];
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    const uint64_t gid = (uint64_t)(b.first_env_id + i);
+
+    // ---- influent_mixed (buffer_tank3.py:68-107): series = mean + std*rnd, flow-weighted means,
+    //      sums accumulated in sample order like python's sum()
+    double ld[SBR_NX];
+    if (need_tables) {
+        int s = scenario ? scenario[i] : 6;                          // :180
+        s = s < 0 ? 0 : (s >= SBR_NSCEN ? SBR_NSCEN - 1 : s);        // never index LDS out of range
+        const double* mu = lds + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
+        const double* sd = lds + kTableDoubles + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
+        double acc[13], sq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 13; ++j) acc[j] = 0.0;
+        for (int kk = 0; kk < SBR_NSAMP; kk += 2) {
+            double z[2];
+            if (rnd) { z[0] = rnd[i * SBR_NSAMP + kk]; z[1] = rnd[i * SBR_NSAMP + kk + 1]; }
+            else sbr_normal_pair(seed, gid, (uint32_t)(kk >> 1), z[0], z[1]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = kk + u;
+                const double q = mu[13 * SBR_NSAMP + k] + sd[13 * SBR_NSAMP + k] * z[u];
+                sq = sq + q;
+#pragma unroll
+                for (int j = 0; j < 13; ++j) acc[j] = acc[j] + (mu[j * SBR_NSAMP + k] + sd[j * SBR_NSAMP + k] * z[u]) * q;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) ld[1 + j] = acc[j] / sq;
+    } else {
+#pragma unroll
+        for (int j = 1; j < SBR_NX; ++j) ld[j] = influent[i * SBR_NX + j];
+    }
+    ld[0] = p.load0;                                                 // :287
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) b.infl[(int64_t)j * b.n + i] = ld[j];
+
+    // ---- fill phase, Sim_filling :1585-1654.  DO-PID at t_start == 0: ie = 0, dcv = 0, set-point 0
+    double x[SBR_NX], x0[SBR_NX];
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) { x[j] = p.x0[j]; x0[j] = p.x0[j]; }
+    SbrCtl c;
+    const double e = 0.0 - x0[8];
+    double ie = 0.0;
+    double kla = p.Kc_DO * e + p.KcI_DO * ie;
+    if (kla > p.Kla_max) { kla = p.Kla_max; ie = ie - e * p.dt; }
+    if (kla < p.Kla_min) { kla = p.Kla_min; ie = ie - e * p.dt; }
+    sbr_rk4<1>(p, x, p.T_fill, p.fill_rows, kla, 0.0, ld);
+    c.t = p.T_fill;
+    c.so_m2 = x0[8]; c.so_m1 = x[8];
+    c.sno_m2 = x0[9]; c.sno_m1 = x[2];                               // :1652 stores Ss in the Sno memory
+    c.ie_do = ie; c.ie_ec = 0.0; c.ec_last = 0.0; c.ec_prev = 0.0;
+    c.u_do = 0.0; c.u_ec = 15.0;                                     // :212-213
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) c.kh[j] = ((SBR_KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;   // [0,k]*126, :323
+    c.qw = 0.0; c.ret = 0.0; c.steps = 0.0; c.done = 0.0;
+    c.status = sbr_status_bits(p, x, 0.0);
+    store_x(b, i, x);
+    store_ctl(b, i, c);
+    if (obs) {   // volume blend of influent and post-fill state, :346-361
+        double xr[SBR_NX];
+#pragma unroll
+        for (int j = 0; j < SBR_NX; ++j) xr[j] = (p.qin * ld[j] + x[j] * p.IV) / (p.qin + p.IV);
+        sbr_write_obs<OutT>(obs + i * SBR_NOBS, c.t, xr, x0, x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- step
+template <typename OutT, typename ActT>
+__global__ __launch_bounds__(SBR_BLOCK) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
+                                                   OutT* __restrict__ obs, OutT* __restrict__ state,
+                                                   OutT* __restrict__ reward, uint8_t* __restrict__ done) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    double x[SBR_NX], xa[SBR_NX];
+    SbrCtl c;
+    load_x(b, i, x);
+    load_ctl(b, i, c);
+    if (c.done != 0.0) {          // finished env: waits for sbr_reset (the reference leaves resetting to the caller)
+        if (reward) reward[i] = (OutT)0;
+        if (done) done[i] = 1;
+        if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, p.t_cycle, x, x, x);
+        if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, p.t_cycle, x);
+        return;
+    }
+    const double a0 = (double)action[2 * i], a1 = (double)action[2 * i + 1];     // one 8- or 16-byte load per lane
+    double t_obs;
+    bool dn;
+    const double r = sbr_step_env(p, c, x, a0, a1, xa, t_obs, dn);
+    store_x(b, i, x);
+    store_ctl(b, i, c);
+    if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, t_obs, x, xa, x);
+    if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, t_obs, x);
+    if (reward) reward[i] = (OutT)r;
+    if (done) done[i] = dn ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------- rollout
+__global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
+                                                      double* __restrict__ returns, float* __restrict__ actions_out) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    const uint64_t gid = (uint64_t)(b.first_env_id + i);
+    double x[SBR_NX], xa[SBR_NX];
+    SbrCtl c;
+    load_x(b, i, x);
+    load_ctl(b, i, c);
+    double acc = 0.0;
+    for (int32_t s = 0; s < n_steps; ++s) {
+        float a0, a1;
+        sbr_policy_action(p, policy_seed, gid, (uint32_t)c.steps, a0, a1);
+        if (actions_out) reinterpret_cast<float2*>(actions_out)[(int64_t)s * b.n + i] = make_float2(a0, a1);
+        if (c.done != 0.0) continue;
+        double t_obs;
+        bool dn;
+        acc += sbr_step_env(p, c, x, (double)a0, (double)a1, xa, t_obs, dn);
+    }
+    store_x(b, i, x);
+    store_ctl(b, i, c);
+    if (returns) returns[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------- stats
+// {sum, min, max, count} of a per-env vector: butterfly over the 64 lanes of each wave (DPP/swizzle via
+// __shfl_xor), then one atomic per wave.
+SBR_DEV double atomic_min_f64(double* addr, double v) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double((long long)assumed) <= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+    return __longlong_as_double((long long)old);
+}
+SBR_DEV double atomic_max_f64(double* addr, double v) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double((long long)assumed) >= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+    return __longlong_as_double((long long)old);
+}
+
+__global__ __launch_bounds__(SBR_BLOCK) void k_stats_init(double* out4) {
+    if (threadIdx.x == 0) { out4[0] = 0.0; out4[1] = INFINITY; out4[2] = -INFINITY; out4[3] = 0.0; }
+}
+
+__global__ __launch_bounds__(SBR_BLOCK) void k_stats(const double* __restrict__ v, int64_t n, double* out4) {
+    double s = 0.0, mn = INFINITY, mx = -INFINITY, cnt = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SBR_BLOCK) {
+        const double a = v[i];
+        s += a; mn = fmin(mn, a); mx = fmax(mx, a); cnt += 1.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        mn = fmin(mn, __shfl_xor(mn, off, 64));
+        mx = fmax(mx, __shfl_xor(mx, off, 64));
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if (threadIdx.x == 0 && cnt > 0.0) {
+        atomicAdd(out4 + 0, s);
+        atomic_min_f64(out4 + 1, mn);
+        atomic_max_f64(out4 + 2, mx);
+        atomicAdd(out4 + 3, cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- helpers
+__global__ __launch_bounds__(SBR_BLOCK) void k_rhs(SbrPar p, int32_t kind, int64_t n, const double* __restrict__ x,
+                                                  const double* __restrict__ kla, const double* __restrict__ ec,
+                                                  const double* __restrict__ loading, double* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double xv[SBR_NX], ld[SBR_NX], d[SBR_NX];
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) { xv[j] = x[i * SBR_NX + j]; ld[j] = loading ? loading[i * SBR_NX + j] : 0.0; }
+    if (kind == 0) sbr_rhs<0>(p, xv, kla[i], ec[i], ld, d);
+    else if (kind == 1) sbr_rhs<1>(p, xv, kla[i], 0.0, ld, d);
+    else sbr_rhs<2>(p, xv, kla[i], 0.0, ld, d);
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) dx[i * SBR_NX + j] = d[j];
+}
+
+__global__ __launch_bounds__(SBR_BLOCK) void k_normals(SbrBuf b, uint64_t seed, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    for (uint32_t k = 0; k < SBR_NSAMP / 2; ++k) {
+        double z0, z1;
+        sbr_normal_pair(seed, (uint64_t)(b.first_env_id + i), k, z0, z1);
+        out[i * SBR_NSAMP + 2 * k] = z0;
+        out[i * SBR_NSAMP + 2 * k + 1] = z1;
+    }
+}
+
+// =========================================================================================== host / C ABI
+struct sbr_env {
+    int64_t n = 0;
+    int device = 0;
+    int64_t first_env_id = 0;
+    sbr_config cfg;
+    SbrPar par;
+    SbrBuf buf{};
+    double* tables = nullptr;     // [2][8][14][48] on the device
+    bool have_tables = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int fail(sbr_env* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIP_TRY(e, call)                                                                              \
+    do {                                                                                              \
+        hipError_t _s = (call);                                                                       \
+        if (_s != hipSuccess)                                                                         \
+            return fail(e, SBR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));           \
+    } while (0)
+
+static void derive_params(const sbr_config& c, SbrPar& p) {
+    p.muH = c.muH; p.Ks = c.Ks; p.Koh = c.Koh; p.Kno = c.Kno; p.bH = c.bH; p.eta_g = c.eta_g; p.eta_h = c.eta_h;
+    p.kh = c.kh; p.Kx = c.Kx; p.muA = c.muA; p.Knh = c.Knh; p.bA = c.bA; p.Koa = c.Koa; p.ka = c.ka;
+    const double Yh = c.Yh, Ya = c.Ya, ixb = c.ixb, ixp = c.ixp, fp = c.fp;
+    p.n2_12 = -1 / Yh; p.n4_45 = 1 - ixp; p.n7_45 = ixp;
+    p.n8_1 = -(1 - Yh) / Yh; p.n8_3 = -(4.57 - Ya) / Ya;
+    p.n9_2 = -((1 - Yh) / (2.86 * Yh)); p.n9_3 = 1 / Ya;
+    p.n10_12 = -ixb; p.n10_3 = -ixb - 1 / Ya;
+    p.n12_45 = ixb - fp * ixp;
+    p.n13_1 = -ixb / 14; p.n13_2 = (1 - Yh) / (14 * 2.86 * Yh) - ixb / 14; p.n13_3 = -ixb / 14 - 1 / (7 * Ya);
+    p.n13_6 = 1.0 / 14;
+    p.WV = c.WV; p.IV = c.IV; p.dt = c.dt; p.t_delta = c.t_delta; p.t_cycle = c.t_cycle;
+    p.T_fill = c.T_fill; p.T3_0 = c.T3_0; p.T3_end = c.T3_end; p.T4_end = c.T4_end; p.T5_end = c.T5_end;
+    p.t_settle = c.t_settle; p.t_draw = c.t_draw;
+    p.qin = c.WV - c.IV; p.load0 = p.qin / c.T_fill;
+    p.So_sat = c.So_sat; p.Kla_min = c.Kla_min; p.Kla_max = c.Kla_max;
+    p.Kc_DO = c.Kc_DO; p.KcI_DO = c.Kc_DO / c.tauI_DO; p.KcD_DO = c.Kc_DO * c.tauD_DO;
+    p.EC_min = c.EC_min; p.EC_max = c.EC_max;
+    p.Kc_EC = c.Kc_EC; p.KcI_EC = c.Kc_EC / c.tauI_EC; p.KcD_EC = c.Kc_EC * c.tauD_EC; p.EC_conc = c.EC_conc;
+    p.act_DO_max = c.act_DO_max; p.act_EC_max = c.act_EC_max;
+    p.biomass_setpoint = c.biomass_setpoint; p.Qeff = c.Qeff; p.settler_area = c.settler_area;
+    p.settler_vmax = c.settler_vmax;
+    memcpy(p.x0, c.x0, sizeof p.x0);
+    p.substeps = c.substeps; p.terminal = c.terminal;
+    p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
+    p.pad_ = 0;
+}
+
+template <typename OutT, typename ActT>
+static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
+                        hipStream_t st) {
+    hipLaunchKernelGGL((k_step<OutT, ActT>), dim3((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK)), dim3(SBR_BLOCK), 0, st,
+                       e->par, e->buf, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+}
+
+extern "C" {
+
+const char* sbr_version(void) { return "sbr_amd 0.1.0 (gfx950, fp64 RK4)"; }
+
+int sbr_default_config(sbr_config* c) {
+    if (!c) return SBR_ERR_INVALID;
+    memset(c, 0, sizeof *c);
+    // SURVEY.md Appendix A; values asserted against tests/golden/constants.npz by tests/test_capi_cpu.py
+    c->Ya = 0.24; c->Yh = 0.67; c->fp = 0.08; c->ixb = 0.08; c->ixp = 0.06;
+    c->muH = 4.0; c->Ks = 10.0; c->Koh = 0.2; c->Kno = 0.5; c->bH = 0.3; c->eta_g = 0.8; c->eta_h = 0.8;
+    c->kh = 3.0; c->Kx = 0.1; c->muA = 0.5; c->Knh = 1.0; c->bA = 0.05; c->Koa = 0.4; c->ka = 0.05;
+    c->WV = 1.32; c->IV = 0.6161484733495801; c->dt = 0.002 / 24; c->t_delta = c->dt * 10; c->t_cycle = 12.0 / 24;
+    c->T_fill = 0.021; c->T3_0 = 0.06416666666666668; c->T3_end = 0.2516666666666667;
+    c->T4_end = 0.4085000000000001; c->T5_end = 0.40933333333333344;
+    c->t_settle = 8.3 / 100; c->t_draw = 2.1 / 100;
+    c->So_sat = 8.000000000006622; c->Kla_min = 0; c->Kla_max = 240; c->Kc_DO = 100; c->tauI_DO = 20; c->tauD_DO = 0;
+    c->EC_min = 0; c->EC_max = 0.0005; c->Kc_EC = 100; c->tauI_EC = 20; c->tauD_EC = 0; c->EC_conc = 1200000 * 4.0;
+    c->act_DO_max = 8; c->act_EC_max = 15;
+    c->biomass_setpoint = 2700; c->Qeff = 0.66; c->settler_area = (1.25 / 2) * (1.25 / 2); c->settler_vmax = 474;
+    static const double x0[SBR_NX] = {0.6161484733495801, 30, 0.571098000538576, 1440.01157895393, 31.254221999137,
+                                      2599.2714348941, 168.915006750837, 551.901552960823, 2.16607843793004,
+                                      13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
+                                      3.790463057094611};
+    memcpy(c->x0, x0, sizeof x0);
+    c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->act_f64 = 0;
+    return SBR_OK;
+}
+
+int sbr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_config* cfg, sbr_env** out) {
+    if (!out) return fail(nullptr, SBR_ERR_INVALID, "sbr_create: out is NULL");
+    *out = nullptr;
+    if (n_envs <= 0) return fail(nullptr, SBR_ERR_INVALID, "sbr_create: n_envs must be > 0");
+    int ndev = sbr_device_count();
+    if (ndev <= 0)
+        return fail(nullptr, SBR_ERR_NO_DEVICE, "sbr_create: no HIP device visible - this library has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, SBR_ERR_INVALID, "sbr_create: bad device_id");
+    sbr_env* e = new sbr_env();
+    e->n = n_envs; e->device = device_id; e->first_env_id = first_env_id;
+    if (cfg) e->cfg = *cfg; else sbr_default_config(&e->cfg);
+    const sbr_config& c = e->cfg;
+    std::string bad;
+    if (c.substeps < 1 || c.substeps > 10000) bad = "substeps out of range";
+    if (!(c.dt > 0) || !(c.t_delta > 0)) bad = "dt and t_delta must be positive";
+    else {
+        const int rows = (int)(c.t_delta / c.dt + 0.5);
+        if (rows != 10) bad = "t_delta must be 10*dt (the reward's Kla look-back is 9 intervals)";
+    }
+    if (!(c.T_fill > 0) || (int)(c.T_fill / c.dt) < 1) bad = "T_fill/dt must be >= 1";
+    if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0)) bad = "tauI must be non-zero";
+    if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }
+    derive_params(c, e->par);
+#define CREATE_TRY(call)                                                                         \
+    do {                                                                                         \
+        hipError_t _s = (call);                                                                  \
+        if (_s != hipSuccess) {                                                                  \
+            std::string m = std::string(#call) + ": " + hipGetErrorString(_s);                   \
+            sbr_destroy(e);                                                                      \
+            return fail(nullptr, _s == hipErrorOutOfMemory ? SBR_ERR_ALLOC : SBR_ERR_HIP, m);    \
+        }                                                                                        \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        std::string m = std::string("sbr_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+        sbr_destroy(e);
+        return fail(nullptr, SBR_ERR_NO_DEVICE, m);
+    }
+    const size_t nb = (size_t)n_envs * sizeof(double);
+    CREATE_TRY(hipMalloc(&e->buf.x, SBR_NX * nb));
+    CREATE_TRY(hipMalloc(&e->buf.ctrl, SBR_NCTRL * nb));
+    CREATE_TRY(hipMalloc(&e->buf.infl, SBR_NX * nb));
+    CREATE_TRY(hipMalloc(&e->tables, 2 * kTableDoubles * sizeof(double)));
+    CREATE_TRY(hipMemset(e->buf.x, 0, SBR_NX * nb));
+    CREATE_TRY(hipMemset(e->buf.ctrl, 0, SBR_NCTRL * nb));
+    CREATE_TRY(hipMemset(e->buf.infl, 0, SBR_NX * nb));
+    // an env is unusable until its first reset: mark everything done so that step() is a no-op until then
+    {
+        std::vector<double> ones((size_t)n_envs, 1.0);
+        CREATE_TRY(hipMemcpy(e->buf.ctrl + (size_t)SBR_C_DONE * n_envs, ones.data(), nb, hipMemcpyHostToDevice));
+    }
+    CREATE_TRY(hipEventCreate(&e->ev0));
+    CREATE_TRY(hipEventCreate(&e->ev1));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<float>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTableDoubles * (int)sizeof(double)));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<double>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTableDoubles * (int)sizeof(double)));
+#undef CREATE_TRY
+    e->buf.n = n_envs; e->buf.first_env_id = first_env_id;
+    *out = e;
+    return SBR_OK;
+}
+
+int sbr_destroy(sbr_env* e) {
+    if (!e) return SBR_OK;
+    (void)hipSetDevice(e->device);
+    if (e->buf.x) (void)hipFree(e->buf.x);
+    if (e->buf.ctrl) (void)hipFree(e->buf.ctrl);
+    if (e->buf.infl) (void)hipFree(e->buf.infl);
+    if (e->tables) (void)hipFree(e->tables);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    delete e;
+    return SBR_OK;
+}
+
+const char* sbr_last_error(const sbr_env* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+int64_t sbr_num_envs(const sbr_env* e) { return e ? e->n : 0; }
+
+int sbr_set_influent_tables(sbr_env* e, const double* means, const double* stds) {
+    if (!e || !means || !stds) return fail(e, SBR_ERR_INVALID, "sbr_set_influent_tables: NULL argument");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpy(e->tables, means, kTableDoubles * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->tables + kTableDoubles, stds, kTableDoubles * sizeof(double), hipMemcpyHostToDevice));
+    e->have_tables = true;
+    return SBR_OK;
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + SBR_BLOCK - 1) / SBR_BLOCK)); }
+
+int sbr_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+              const uint8_t* mask, void* obs, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    if (!influent && !e->have_tables)
+        return fail(e, SBR_ERR_INVALID, "sbr_reset: no influent given and sbr_set_influent_tables was never called");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
+    if (e->cfg.out_f64)
+        hipLaunchKernelGGL(k_reset<double>, grid_for(e->n), dim3(SBR_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
+                           scenario, rnd, influent, mask, (double*)obs);
+    else
+        hipLaunchKernelGGL(k_reset<float>, grid_for(e->n), dim3(SBR_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
+                           scenario, rnd, influent, mask, (float*)obs);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done, void* stream) {
+    if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_step: NULL env or action");
+    hipStream_t st = (hipStream_t)stream;
+    if (e->cfg.out_f64) {
+        if (e->cfg.act_f64) launch_step<double, double>(e, action, obs, state, reward, done, st);
+        else launch_step<double, float>(e, action, obs, state, reward, done, st);
+    } else {
+        if (e->cfg.act_f64) launch_step<float, double>(e, action, obs, state, reward, done, st);
+        else launch_step<float, float>(e, action, obs, state, reward, done, st);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
+    if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
+    hipLaunchKernelGGL(k_rollout, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
+                       policy_seed, returns, actions_out);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_reduce_stats(sbr_env* e, const double* values, int64_t n, double* out4, void* stream) {
+    if (!e || !values || !out4 || n < 0) return fail(e, SBR_ERR_INVALID, "sbr_reduce_stats: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(SBR_BLOCK), 0, st, out4);
+    if (n > 0) {
+        int64_t blocks = (n + SBR_BLOCK - 1) / SBR_BLOCK;
+        if (blocks > 2048) blocks = 2048;      // grid-stride beyond 8 waves per CU
+        hipLaunchKernelGGL(k_stats, dim3((unsigned)blocks), dim3(SBR_BLOCK), 0, st, values, n, out4);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_get_state(sbr_env* e, double* x, double* ctrl, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    const size_t nb = (size_t)e->n * sizeof(double);
+    if (x) HIP_TRY(e, hipMemcpyAsync(x, e->buf.x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ctrl) HIP_TRY(e, hipMemcpyAsync(ctrl, e->buf.ctrl, SBR_NCTRL * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SBR_OK;
+}
+
+int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    const size_t nb = (size_t)e->n * sizeof(double);
+    if (x) HIP_TRY(e, hipMemcpyAsync(e->buf.x, x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ctrl) HIP_TRY(e, hipMemcpyAsync(e->buf.ctrl, ctrl, SBR_NCTRL * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SBR_OK;
+}
+
+int sbr_get_influent(sbr_env* e, double* out, void* stream) {
+    if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_get_influent: NULL argument");
+    HIP_TRY(e, hipMemcpyAsync(out, e->buf.infl, SBR_NX * (size_t)e->n * sizeof(double), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+    return SBR_OK;
+}
+
+int sbr_eval_rhs(sbr_env* e, int32_t kind, int64_t n, const double* x, const double* kla, const double* ec,
+                 const double* loading, double* dx, void* stream) {
+    if (!e || !x || !kla || !ec || !dx || kind < 0 || kind > 2 || (kind == 1 && !loading))
+        return fail(e, SBR_ERR_INVALID, "sbr_eval_rhs: bad argument");
+    if (n > 0)
+        hipLaunchKernelGGL(k_rhs, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, kind, n, x, kla, ec,
+                           loading, dx);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_draw_normals(sbr_env* e, uint64_t seed, double* out, void* stream) {
+    if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_draw_normals: NULL argument");
+    hipLaunchKernelGGL(k_normals, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->buf, seed, out);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_timer_start(sbr_env* e, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    HIP_TRY(e, hipEventRecord(e->ev0, (hipStream_t)stream));
+    return SBR_OK;
+}
+
+int sbr_timer_stop(sbr_env* e, void* stream, float* elapsed_ms) {
+    if (!e || !elapsed_ms) return SBR_ERR_INVALID;
+    HIP_TRY(e, hipEventRecord(e->ev1, (hipStream_t)stream));
+    HIP_TRY(e, hipEventSynchronize(e->ev1));
+    HIP_TRY(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
+    return SBR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// sbr_device.h - device functions of the batched SBR environment (gfx950 / CDNA4, fp64 VALU).
+//
+// Mapping: ONE LANE PER ENVIRONMENT.  The plant (14 states) and both controllers of an env live in
+// that lane's VGPRs; every constant of the model is wave-uniform and arrives through the kernel
+// argument segment, i.e. in SGPRs via scalar loads (no VGPR and no LDS traffic for constants).
+// Plant/controller state is struct-of-arrays [field][N] float64 in HBM, so a wave's load of one field
+// is one contiguous 512-byte segment.  There is nothing GEMM-shaped here: no MFMA.
+//
+// Every function cites the reference lines it replaces
+// (/root/reference/gym_SBR/envs/gym_SBR_oneshot.py unless another file is named).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sbr_amd.h"
+
+#define SBR_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-uniform model constants: sbr_config + everything that can be folded on the host (in fp64,
+// with the same expressions the reference evaluates per RHS call, :1689-1725).
+struct SbrPar {
+    // kinetics
+    double muH, Ks, Koh, Kno, bH, eta_g, eta_h, kh, Kx, muA, Knh, bA, Koa, ka;
+    // stoichiometry, folded
+    double n2_12;    // -1/Yh                       (nu2_1 = nu2_2)
+    double n4_45;    // 1 - ixp                     (nu4_4 = nu4_5)
+    double n7_45;    // ixp
+    double n8_1;     // -(1-Yh)/Yh
+    double n8_3;     // -(4.57-Ya)/Ya
+    double n9_2;     // -((1-Yh)/(2.86*Yh))
+    double n9_3;     // 1/Ya
+    double n10_12;   // -ixb
+    double n10_3;    // -ixb - 1/Ya
+    double n12_45;   // ixb - fp*ixp
+    double n13_1;    // -ixb/14
+    double n13_2;    // (1-Yh)/(14*2.86*Yh) - ixb/14
+    double n13_3;    // -ixb/14 - 1/(7*Ya)
+    double n13_6;    // 1/14
+    // plant, time grid
+    double WV, IV, dt, t_delta, t_cycle, T_fill, T3_0, T3_end, T4_end, T5_end, t_settle, t_draw;
+    double qin;          // WV - IV
+    double load0;        // qin / T_fill                                   (:287)
+    // controllers
+    double So_sat, Kla_min, Kla_max, Kc_DO, KcI_DO, KcD_DO;   // KcI = Kc/tauI, KcD = Kc*tauD  (:1898-1900)
+    double EC_min, EC_max, Kc_EC, KcI_EC, KcD_EC, EC_conc;
+    double act_DO_max, act_EC_max;
+    // terminal
+    double biomass_setpoint, Qeff, settler_area, settler_vmax;
+    double x0[SBR_NX];
+    int32_t substeps, terminal, fill_rows, pad_;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Conversion rates r[i] of the 11 reacting components (Si, Xi and V do not react), incl. aeration.
+// Process rates :1660-1685, combination :1731-1755.  Same association order as the reference; FMA
+// contraction by the compiler is allowed (parity is to tolerance, not bitwise).
+SBR_DEV void sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double kla, double (&r)[SBR_NX]) {
+    const double ss = x[2], xs = x[4], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10], snd = x[11],
+                 xnd = x[12];
+    const double m_ss = ss / (p.Ks + ss);
+    const double m_so = so / (p.Koh + so);
+    const double i_so = p.Koh / (so + p.Koh);
+    const double m_no = sno / (p.Kno + sno);
+    const double rho1 = p.muH * m_ss * m_so * xbh;
+    const double rho2 = p.muH * m_ss * i_so * m_no * p.eta_g * xbh;
+    const double rho3 = p.muA * (snh / (p.Knh + snh)) * (so / (p.Koa + so)) * xba;
+    const double rho4 = p.bH * xbh;
+    const double rho5 = p.bA * xba;
+    const double rho6 = p.ka * snd * xbh;
+    const double ratio = xs / xbh;
+    const double rho7 = p.kh * (ratio / (p.Kx + ratio)) * (m_so + p.eta_h * i_so * m_no) * xbh;
+    const double rho8 = (xnd / xs) * rho7;
+    r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
+    r[2] = p.n2_12 * rho1 + p.n2_12 * rho2 + rho7;
+    r[4] = p.n4_45 * rho4 + p.n4_45 * rho5 - rho7;
+    r[5] = rho1 + rho2 - rho4;
+    r[6] = rho3 - rho5;
+    r[7] = p.n7_45 * rho4 + p.n7_45 * rho5;
+    r[8] = p.n8_1 * rho1 + p.n8_3 * rho3 + kla * (p.So_sat - so);
+    r[9] = p.n9_2 * rho2 + p.n9_3 * rho3;
+    r[10] = p.n10_12 * rho1 + p.n10_12 * rho2 + p.n10_3 * rho3 + rho6;
+    r[11] = rho8 - rho6;
+    r[12] = p.n12_45 * rho4 + p.n12_45 * rho5 - rho8;
+    r[13] = p.n13_1 * rho1 + p.n13_2 * rho2 + p.n13_3 * rho3 + p.n13_6 * rho6;
+}
+
+// Right-hand sides.  KIND 0: reaction_dxdt :1658-1787 (dosing ec, dilution ec/V)
+//                    KIND 1: filling_dxdt :1424-1583 at EC = 0 (loading vector ld, ld[0] = inflow)
+//                    KIND 2: idle_dxdt :2424-2552 (conversion only)
+//                    KIND 3: reaction with ec == 0 for every lane of the wave: V, Si, Xi are constant
+template <int KIND>
+SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, double ec, const double (&ld)[SBR_NX],
+                     double (&d)[SBR_NX]) {
+    double r[SBR_NX];
+    sbr_conversion(p, x, kla, r);
+    if (KIND == 0) {
+        const double q = ec / x[0];
+        d[0] = ec;
+#pragma unroll
+        for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (i == 2 ? (p.EC_conc - x[i]) : (-x[i]));
+    } else if (KIND == 1) {
+        const double q = ld[0] / x[0];
+        d[0] = ld[0];
+#pragma unroll
+        for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (ld[i] - x[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SBR_NX; ++i) d[i] = r[i];
+    }
+}
+
+// Classical RK4, n equal substeps over `span`; autonomous inside a span (Kla, EC held).  Low-storage
+// form: x, the running combination and one stage vector are live (3 x 14 doubles).
+template <int KIND>
+SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double span, int n, double kla, double ec,
+                     const double (&ld)[SBR_NX]) {
+    const double h = span / (double)n;
+    const double h2 = 0.5 * h, h6 = h / 6.0, h3 = h / 3.0;
+    for (int s = 0; s < n; ++s) {
+        double k[SBR_NX], y[SBR_NX], acc[SBR_NX];
+        sbr_rhs<KIND>(p, x, kla, ec, ld, k);
+#pragma unroll
+        for (int i = 0; i < SBR_NX; ++i) { acc[i] = x[i] + h6 * k[i]; y[i] = x[i] + h2 * k[i]; }
+        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+#pragma unroll
+        for (int i = 0; i < SBR_NX; ++i) { acc[i] += h3 * k[i]; y[i] = x[i] + h2 * k[i]; }
+        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+#pragma unroll
+        for (int i = 0; i < SBR_NX; ++i) { acc[i] += h3 * k[i]; y[i] = x[i] + h * k[i]; }
+        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+#pragma unroll
+        for (int i = 0; i < SBR_NX; ++i) x[i] = acc[i] + h6 * k[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-env controller / bookkeeping registers (mirrors the ctrl rows of sbr_amd.h)
+struct SbrCtl {
+    double t, so_m1, so_m2, sno_m1, sno_m2, ie_do, ie_ec, ec_last, ec_prev, u_do, u_ec;
+    double kh[SBR_KLA_HIST];   // Kla history, oldest first; kh[9] = Kla[-1]
+    double qw, ret, steps, done, status;
+    // of the last interval (not stored): span = t_range[-1]-t_range[0], rows = len(t_range) (9 or 10)
+    double span;
+    int rows;
+};
+
+// Sticky domain-of-validity bits (SBR_ST_* in sbr_amd.h), evaluated on the end state of an interval.  x < -K/2 is
+// "within 50 % of the pole of x/(K+x)".  Pure bookkeeping: nothing in the dynamics reads it.
+SBR_DEV double sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX], double status) {
+    int st = (int)status;
+    const double lo = -1e-6;
+    if (x[2] < lo || x[4] < lo || x[5] < lo || x[8] < lo || x[9] < lo || x[10] < lo) st |= SBR_ST_NEGATIVE;
+    const double ko = p.Koh < p.Koa ? p.Koh : p.Koa;
+    if (x[2] < -0.5 * p.Ks || x[8] < -0.5 * ko || x[9] < -0.5 * p.Kno || x[10] < -0.5 * p.Knh) st |= SBR_ST_NEAR_POLE;
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < SBR_NX; ++i) sum += x[i];
+    if (!(fabs(sum) < 1.7e308)) st |= SBR_ST_NONFINITE;          // NaN or inf anywhere
+    return (double)st;
+}
+
+// One control interval: Sim_aero_rxn :1877-1963 / Sim_anaero_rxn :1965-2051, run_*_step :1331-1419.
+// xs receives the interval's start state (for xdot).
+SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double (&xs)[SBR_NX], bool aerobic) {
+    const double t0 = c.t, t1 = t0 + p.t_delta;
+    const double span = t1 - t0;
+    c.rows = (int)(span / p.dt);              // 9 or 10: fp rounding of (t+t_delta)-t   (:1339, :1384)
+    c.rows = c.rows < 2 ? 2 : (c.rows > SBR_KLA_HIST ? SBR_KLA_HIST : c.rows);   // bounded even if t was injected as garbage
+    // DO-PID -> Kla (velocity form: bias is the previous Kla).  In anoxic intervals the output is forced to 0
+    // but the integral keeps winding with set-point 0 (:1974-1997).
+    const double e = (aerobic ? c.u_do : 0.0) - c.so_m1;
+    const double dcv = (c.so_m1 - c.so_m2) / p.dt;
+    c.ie_do = c.ie_do + e * p.dt;
+    double kla = aerobic ? (p.Kc_DO * e + p.KcI_DO * c.ie_do + p.KcD_DO * dcv + c.kh[SBR_KLA_HIST - 1]) : 0.0;
+    if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - e * p.dt; }
+    if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - e * p.dt; }
+    // NO3-PID -> EC (error sign reversed, :2006); forced to 0 in aerobic intervals while its integral winds (:1918-1937)
+    const double e2 = c.sno_m1 - c.u_ec;
+    const double dcv2 = (c.sno_m1 - c.sno_m2) / p.dt;
+    c.ie_ec = c.ie_ec + e2 * p.dt;
+    double ec = aerobic ? 0.0 : (p.Kc_EC * e2 + p.KcI_EC * c.ie_ec + p.KcD_EC * dcv2 + c.ec_last);
+    if (ec < p.EC_min) { ec = p.EC_min; c.ie_ec = c.ie_ec - e2 * p.dt; }
+    else if (ec > p.EC_max) { ec = p.EC_max; c.ie_ec = c.ie_ec - e2 * p.dt; }
+#pragma unroll
+    for (int i = 0; i < SBR_NX; ++i) xs[i] = x[i];
+    // wave-uniform choice: if no lane doses, V/Si/Xi are constants of the interval
+    const double (&nold)[SBR_NX] = xs;
+    if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<3>(p, x, span, p.substeps, kla, 0.0, nold);
+    else sbr_rk4<0>(p, x, span, p.substeps, kla, ec, nold);
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) c.kh[j] = c.kh[j + 1];
+    c.kh[SBR_KLA_HIST - 1] = kla;
+    c.ec_prev = c.ec_last; c.ec_last = ec;
+    c.so_m2 = c.so_m1; c.so_m1 = x[8];
+    c.sno_m2 = c.sno_m1; c.sno_m1 = x[9];
+    c.t = t1; c.span = span;
+    c.status = sbr_status_bits(p, x, c.status);
+}
+
+// module_reward_EQIOCI.py:4-115.  Kla got one append per interval, EC got rows-1:  Kla[-rows:-1] is
+// the rows-1 values BEFORE the current one, EC[-rows:-1] = last value of the previous interval +
+// (rows-2) x current.
+SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&x)[SBR_NX]) {
+    const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
+    const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
+    const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
+    const double bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * (xbh + xba));
+    const double cod = x[2] + x[1] + xs + xi + xbh + xba + xp;
+    const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
+    const double eqi2 = eqi / 10;
+    const double td = 0.002 / 24;
+    double ksum = (c.rows >= 10) ? c.kh[0] : 0.0;          // 9 previous values if rows == 10, else 8
+#pragma unroll
+    for (int j = 1; j < SBR_KLA_HIST - 1; ++j) ksum = ksum + c.kh[j];
+    const double ae = 8 / (c.span * 1.8 * 1000) * (1.32 * ksum * td);
+    double esum = c.ec_prev;
+    for (int j = 0; j < c.rows - 2; ++j) esum = esum + c.ec_last;
+    const double ec_oci = p.EC_conc * esum * td / (c.span * 1000);
+    const double oci = ae + ec_oci;
+    return (1 - (eqi2 * eqi2 + oci * oci)) / 473;
+}
+
+SBR_DEV double sbr_clip1(double v) { return v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v); }
+
+// obs_DO ++ obs_EC :1027-1114 (normalisers :150-156, xdot scales :1069-1076).  xr: what is reported,
+// xa -> xb: span of the clipped state change.
+template <typename OutT>
+SBR_DEV void sbr_write_obs(OutT* __restrict__ o, double t_obs, const double (&xr)[SBR_NX], const double (&xa)[SBR_NX],
+                           const double (&xb)[SBR_NX]) {
+    const double tt = t_obs / 0.5;
+    const double dxh = sbr_clip1((xb[5] - xa[5]) / 4000), dsnh = sbr_clip1((xb[10] - xa[10]) / 50);
+    o[0] = (OutT)tt; o[1] = (OutT)(xr[5] / 2000); o[2] = (OutT)(xr[6] / 500); o[3] = (OutT)(xr[8] / 8.0);
+    o[4] = (OutT)(xr[10] / 10);
+    o[5] = (OutT)dxh; o[6] = (OutT)sbr_clip1((xb[6] - xa[6]) / 500); o[7] = (OutT)sbr_clip1((xb[8] - xa[8]) / 8);
+    o[8] = (OutT)dsnh;
+    o[9] = (OutT)tt; o[10] = (OutT)(xr[2] / 30); o[11] = (OutT)(xr[5] / 2000); o[12] = (OutT)(xr[9] / 10);
+    o[13] = (OutT)(xr[10] / 10);
+    o[14] = (OutT)sbr_clip1((xb[2] - xa[2]) / 50); o[15] = (OutT)dxh; o[16] = (OutT)sbr_clip1((xb[9] - xa[9]) / 50);
+    o[17] = (OutT)dsnh;
+}
+
+// state = [t, x] / x_1_state  (:153, :1020-1025)
+template <typename OutT>
+SBR_DEV void sbr_write_state(OutT* __restrict__ s, double t_obs, const double (&x)[SBR_NX]) {
+    s[0] = (OutT)(t_obs / 0.5); s[1] = (OutT)(x[0] / 1.32); s[2] = (OutT)(x[1] / 30); s[3] = (OutT)(x[2] / 30);
+    s[4] = (OutT)(x[3] / 1500); s[5] = (OutT)(x[4] / 150); s[6] = (OutT)(x[5] / 3000); s[7] = (OutT)(x[6] / 2000);
+    s[8] = (OutT)(x[7] / 600); s[9] = (OutT)(x[8] / 8); s[10] = (OutT)(x[9] / 20); s[11] = (OutT)(x[10] / 20);
+    s[12] = (OutT)(x[11] / 10); s[13] = (OutT)(x[12] / 10); s[14] = (OutT)(x[13] / 10);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Terminal phases of the last call of an episode: settle (:2171-2262; v == vmax always, so the layer
+// system is linear and has the closed form below), draw + wastage (:2327-2393), idle (:2554-2597).
+SBR_DEV void sbr_terminal(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX]) {
+    const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
+    const double vs = x[0], z = vs / p.settler_area;
+    const double t_set = p.t_settle * p.t_cycle;
+    const double a = p.settler_vmax / z * t_set, ea = exp(-a);
+    // sX[9-j] = Xf e^-a sum_{m<=j} a^m/m!, sX[0] = 10 Xf - sum(others)
+    double sx[10], term = 1.0, partial = 0.0, others = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= a / (double)(j + 1); }
+#pragma unroll
+    for (int j = 1; j < 10; ++j) others += sx[j];
+    sx[0] = 10.0 * xf - others;
+    const double t_after_draw = (c.t + t_set) + p.t_draw * p.t_cycle;
+    const double layer_v = vs / 10;
+    double resid_v = vs - p.Qeff;
+    int m = (int)ceil(rint(p.Qeff / layer_v));        // python round() is half-to-even = rint
+    m = m < 1 ? 1 : (m > 9 ? 9 : m);
+    const int nl = 10 - m;                            // layers that stay
+    double wsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) if (i < nl) wsum = wsum + layer_v * sx[i];
+    double waste = wsum - p.biomass_setpoint * resid_v;
+    double qw = __builtin_nan("");
+    bool open = true;
+    double wkeep = 0.0;                               // sum of the weights that remain, in layer order
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i < nl) {
+            double w = layer_v * sx[i];
+            if (open) {
+                const double rest = waste - w;
+                if (rest > 0) { waste = rest; w = 0.0; resid_v -= layer_v; }
+                else { qw = waste / (sx[i] - p.biomass_setpoint); w = w - qw * sx[i]; resid_v -= qw; open = false; }
+            }
+            wkeep = wkeep + w;
+        }
+    }
+    const double sx2 = wkeep / resid_v;
+    x[0] = resid_v;
+#pragma unroll
+    for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
+    c.qw = qw;
+    // idle: one DO-PID update (So[-1] == So[-2] == x[8] after settle/draw => dcv = 0), then conversion only
+    const double e = c.u_do - x[8];
+    c.ie_do = c.ie_do + e * p.dt;
+    double kla = p.Kc_DO * e + p.KcI_DO * c.ie_do + c.kh[SBR_KLA_HIST - 1];
+    if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - e * p.dt; }
+    if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - e * p.dt; }
+    const double span = p.t_cycle - t_after_draw;
+    int n = (int)(span / p.dt);                       // 464 for the reference's schedule
+    n = n < 0 ? 0 : (n > 100000 ? 100000 : n);        // every wave terminates whatever t holds
+    const double (&nold)[SBR_NX] = x;
+    double xi[SBR_NX];
+#pragma unroll
+    for (int i = 0; i < SBR_NX; ++i) xi[i] = x[i];
+    sbr_rk4<2>(p, xi, span, n, kla, 0.0, nold);
+#pragma unroll
+    for (int i = 0; i < SBR_NX; ++i) x[i] = xi[i];
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) c.kh[j] = c.kh[j + 1];
+    c.kh[SBR_KLA_HIST - 1] = kla;
+}
+
+// SbrOS.step :843-1273 for one env held in registers.  Returns the reward; xa = start of the xdot
+// span, t_obs = time the observation reports, dn = done flag.
+SBR_DEV double sbr_step_env(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1,
+                            double (&xa)[SBR_NX], double& t_obs, bool& dn) {
+    a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
+    a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
+    // four sequential tests on the running time (:860, :896, :931, :963): a call that crosses a phase
+    // boundary runs a second interval.  Envs reset together are in lockstep, so these branches are
+    // wave-uniform in practice; divergent waves are still correct.
+    if (c.t < p.T3_0) { c.u_ec = a1; c.u_do = 0.0; sbr_interval(p, c, x, xa, false); }
+    if (c.t >= p.T3_0 && c.t <= p.T3_end) { c.u_do = a0; c.u_ec = 0.0; sbr_interval(p, c, x, xa, true); }
+    if (c.t > p.T3_end && c.t <= p.T4_end) { c.u_ec = a1; c.u_do = 0.0; sbr_interval(p, c, x, xa, false); }
+    if (c.t > p.T4_end) { c.u_do = a0; c.u_ec = 0.0; sbr_interval(p, c, x, xa, true); }
+    const double r = sbr_reward(p, c, x);
+    c.ret += r; c.steps += 1.0;
+    t_obs = c.t;
+    dn = false;
+    if (c.t >= p.T5_end) {                                               // :1122
+        dn = true; c.done = 1.0;
+        if (p.terminal) {
+#pragma unroll
+            for (int i = 0; i < SBR_NX; ++i) xa[i] = x[i];
+            sbr_terminal(p, c, x);
+            t_obs = p.t_cycle;
+        }
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  counter = (i, stream, env_lo, env_hi), key = seed.
+SBR_DEV void sbr_philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+SBR_DEV double sbr_u53(uint32_t hi, uint32_t lo) {     // uniform in (0, 1]
+    const uint64_t v = (((uint64_t)hi << 32) | lo) >> 11;
+    return ((double)v + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+// two standard normals: Box-Muller on Philox block i of stream 0
+SBR_DEV void sbr_normal_pair(uint64_t seed, uint64_t env_id, uint32_t i, double& z0, double& z1) {
+    uint32_t c[4] = {i, 0u, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    sbr_philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = sbr_u53(c[0], c[1]), u2 = sbr_u53(c[2], c[3]);
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    z0 = rad * cs; z1 = rad * sn;
+}
+
+// uniform random action of call `call` (stream 1), float32 like the action tensors of sbr_step
+SBR_DEV void sbr_policy_action(const SbrPar& p, uint64_t seed, uint64_t env_id, uint32_t call, float& a0, float& a1) {
+    uint32_t c[4] = {call, 1u, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    sbr_philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    a0 = (float)(sbr_u53(c[0], c[1]) * p.act_DO_max);
+    a1 = (float)(sbr_u53(c[2], c[3]) * p.act_EC_max);
+}

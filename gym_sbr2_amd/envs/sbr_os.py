@@ -1,0 +1,95 @@
+"""`SbrOS` - the reference's single-environment class (gym_SBR/envs/gym_SBR_oneshot.py:99,
+id `SBROS-v1`) with the same surface, backed by the batched HIP environment at N = 1.
+
+    reset()                      -> (obs_DO: list[9], obs_EC: list[9])                     (:438)
+    step([u_DO, u_EC])           -> (obs, state: ndarray[15], reward: float, done: bool, {})  (:1273)
+    get_available_actions(...)   -> [ndarray, ndarray]                                     (:440-459)
+
+Outputs are float64 like the reference's.  Differences, all deliberate: state lives on the GPU
+instead of module globals (so several instances can coexist), the influent noise comes from an
+explicit `seed`/`rnd` instead of the global numpy RNG, and `trajectory()` returns what this
+build records (per-call rewards and states), not the reference's 18 growing lists.
+"""
+import numpy as np
+import torch
+
+from ..vec_env import SbrOSVec
+
+
+class _Box:
+    """Just enough of gym.spaces.Box when neither gym nor gymnasium is installed."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low, self.high = np.asarray(low, dtype=dtype), np.asarray(high, dtype=dtype)
+        self.shape, self.dtype = self.low.shape, dtype
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+class SbrOS:
+    metadata = {"render.modes": ["human"]}                      # :101
+
+    def __init__(self, device=0, seed=None):
+        # the reference declares stale spaces (:106-113); these are the real ones of step()
+        self.action_space = _Box([0.0, 0.0], [8.0, 15.0])
+        self.observation_space = _Box(np.full(18, -np.inf), np.full(18, np.inf))
+        self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64)
+        self._seed = seed
+        self._episodes = 0
+        self._rewards, self._states = [], []
+
+    def seed(self, seed=None):
+        self._seed = seed
+        return [seed]
+
+    def _split(self, obs_row):
+        o = obs_row.tolist()
+        return o[:9], o[9:]
+
+    def reset(self, rnd=None, scenario=None, influent=None):
+        """rnd: the 48 standard normals buffer_tank3.py:68 would draw (None: drawn on the device from
+        `seed` + episode count); scenario: 0..7 (None = 6, as the reference :180)."""
+        seed = (0 if self._seed is None else int(self._seed)) + self._episodes
+        self._episodes += 1
+        self._rewards, self._states = [], []
+        obs = self._vec.reset(seed=seed,
+                              scenario=None if scenario is None else [int(scenario)],
+                              rnd=None if rnd is None else np.asarray(rnd, dtype=np.float64)[None],
+                              influent=None if influent is None else np.asarray(influent, dtype=np.float64)[None])
+        return self._split(obs[0].cpu())
+
+    def step(self, action):
+        a = torch.tensor([[float(action[0]), float(action[1])]], dtype=torch.float64)
+        obs, state, reward, done = self._vec.step(a)
+        obs, state = obs[0].cpu(), state[0].cpu().numpy()
+        reward, done = float(reward[0].item()), bool(done[0].item())
+        self._rewards.append(reward)
+        self._states.append(state)
+        return self._split(obs), state, reward, done, {}
+
+    def get_available_actions(self, pre_action, n_agents, n_action):
+        """Mask of the discrete set-point moves that stay inside the action bounds (:440-459)."""
+        deltas = ([-0.1, 0, 0.1], [-5, 0, 5])
+        bounds = ([0, 8], [0, 15])
+        out = []
+        for agent in range(n_agents):
+            ok = np.ones(n_action)
+            for i in range(n_action):
+                v = pre_action[agent] + deltas[agent][i]
+                ok[i] = 1 if bounds[agent][0] <= v <= bounds[agent][1] else 0
+            out.append(ok)
+        return out
+
+    def trajectory(self):
+        return {"reward_t": list(self._rewards), "state_t": [s.copy() for s in self._states]}
+
+    def render(self, mode="human"):
+        return None
+
+    def close(self):
+        self._vec.close()

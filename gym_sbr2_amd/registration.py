@@ -1,0 +1,37 @@
+"""Environment ids.  The reference registers ten ids (gym_SBR/__init__.py:3-12); this build
+implements the hot path only, `SBROS-v1`.  The other nine raise a clear error (most of them cannot
+run in the reference either)."""
+import importlib
+
+_REGISTRY = {"SBROS-v1": "gym_sbr2_amd.envs:SbrOS"}
+_NOT_BUILT = ["SBR-v0", "SBR-v1", "SBR-v2", "SBR-v4", "SBRCnt-v0", "SBRCnt-v1", "SBRCnt-v2", "SBRCntMA-v1",
+              "SBROS-v2"]
+
+
+def registered_ids():
+    return sorted(_REGISTRY)
+
+
+def make(env_id, **kwargs):
+    if env_id in _NOT_BUILT:
+        raise NotImplementedError("%s is outside the hot path this build accelerates (only SBROS-v1)" % env_id)
+    if env_id not in _REGISTRY:
+        raise KeyError("unknown environment id %r; available: %s" % (env_id, registered_ids()))
+    mod, cls = _REGISTRY[env_id].split(":")
+    return getattr(importlib.import_module(mod), cls)(**kwargs)
+
+
+def register_with_gym():
+    """Register SBROS-v1 with gym / gymnasium if either is installed (neither is in this image)."""
+    done = []
+    for name in ("gymnasium", "gym"):
+        try:
+            reg = importlib.import_module(name + ".envs.registration")
+        except Exception:
+            continue
+        try:
+            reg.register(id="SBROS-v1", entry_point=_REGISTRY["SBROS-v1"])
+            done.append(name)
+        except Exception:
+            pass
+    return done

@@ -1,0 +1,186 @@
+"""Batched SBROS-v1 environment on one MI355X: the host-side mirror of the reference's SbrOS
+(gym_SBR/envs/gym_SBR_oneshot.py:99) for N independent reactors.
+
+PyTorch is used for device memory and streams only; every number comes out of libsbr_amd.so
+(HIP kernels) through the C ABI of include/sbr_amd.h.  There is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _capi
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "influent_tables.npz")
+
+
+def load_influent_tables():
+    """The eight influent scenarios of buffer_tank3.py:18-1197 as data: means, stds [8][14][48]
+    (13 concentrations + flow q; captured from the reference by oracle/gen_golden.py)."""
+    t = np.load(_DATA)
+    return np.ascontiguousarray(t["means"], dtype=np.float64), np.ascontiguousarray(t["stds"], dtype=np.float64)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class SbrOSVec:
+    """N SBROS-v1 environments on one GPU.
+
+    reset()  -> obs [N,18]                         (SbrOS.reset, :168-438; obs_DO[9] ++ obs_EC[9])
+    step(a)  -> obs [N,18], state [N,15], reward [N], done [N] uint8   (SbrOS.step, :843-1273)
+    action a: [N,2] float32 (or float64 with action_dtype=torch.float64, what the reference's step() receives)
+    = (DO set-point, NO3 set-point), clipped to [0,8] x [0,15] as in the reference.
+    """
+
+    def __init__(self, num_envs, device=0, first_env_id=0, out_dtype=torch.float32, config=None, tables=None,
+                 action_dtype=torch.float32):
+        if not torch.cuda.is_available():
+            raise _capi.SbrError("SbrOSVec needs a HIP device (torch.cuda.is_available() is False); "
+                                 "this package has no CPU fallback")
+        self.lib = _capi.load()
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.first_env_id = int(first_env_id)
+        self.cfg = config if config is not None else _capi.default_config()
+        if out_dtype not in (torch.float32, torch.float64):
+            raise ValueError("out_dtype must be torch.float32 or torch.float64")
+        self.out_dtype = out_dtype
+        self.cfg.out_f64 = 1 if out_dtype == torch.float64 else 0
+        if action_dtype not in (torch.float32, torch.float64):
+            raise ValueError("action_dtype must be torch.float32 or torch.float64")
+        self.action_dtype = action_dtype
+        self.cfg.act_f64 = 1 if action_dtype == torch.float64 else 0
+        self._h = C.c_void_p()
+        _capi.check(self.lib.sbr_create(self.num_envs, self.device.index, self.first_env_id, C.byref(self.cfg),
+                                        C.byref(self._h)))
+        means, stds = tables if tables is not None else load_influent_tables()
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        stds = np.ascontiguousarray(stds, dtype=np.float64)
+        assert means.shape == stds.shape == (_capi.NSCEN, _capi.NSERIES, _capi.NSAMP)
+        _capi.check(self.lib.sbr_set_influent_tables(self._h, means.ctypes.data_as(C.c_void_p),
+                                                     stds.ctypes.data_as(C.c_void_p)), self._h)
+        n, dev = self.num_envs, self.device
+        self.obs = torch.empty((n, _capi.NOBS), dtype=out_dtype, device=dev)
+        self.state = torch.empty((n, _capi.NSTATE), dtype=out_dtype, device=dev)
+        self.reward = torch.empty((n,), dtype=out_dtype, device=dev)
+        self.done = torch.empty((n,), dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype, shape):
+        if a is None:
+            return None
+        t = torch.as_tensor(a, dtype=dtype, device=self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.sbr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the gym-like surface
+    def reset(self, seed=0, scenario=None, rnd=None, influent=None, mask=None):
+        n = self.num_envs
+        sc = self._dev(scenario, torch.int32, (n,))
+        rn = self._dev(rnd, torch.float64, (n, _capi.NSAMP))
+        inf = self._dev(influent, torch.float64, (n, _capi.NX))
+        mk = self._dev(mask, torch.uint8, (n,))
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.sbr_reset(self._h, C.c_uint64(int(seed)), _ptr(sc), _ptr(rn), _ptr(inf), _ptr(mk),
+                                           _ptr(self.obs), self._stream()), self._h)
+        self._keep = (sc, rn, inf, mk)      # keep inputs alive until the stream has consumed them
+        return self.obs
+
+    def step(self, action):
+        a = action if (isinstance(action, torch.Tensor) and action.dtype == self.action_dtype and action.is_contiguous()
+                       and action.device == self.device) else self._dev(action, self.action_dtype, (self.num_envs, 2))
+        if tuple(a.shape) != (self.num_envs, 2):
+            raise ValueError("action must have shape [N,2]")
+        _capi.check(self.lib.sbr_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.state), _ptr(self.reward),
+                                      _ptr(self.done), self._stream()), self._h)
+        self._keep_a = a
+        return self.obs, self.state, self.reward, self.done
+
+    def rollout(self, n_steps, policy_seed=0, return_actions=False):
+        """n_steps fused step() calls per env with the on-device uniform random policy; returns the
+        per-env sum of rewards [N] float64 (and the sampled actions [n_steps,N,2] float32)."""
+        ret = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
+        acts = (torch.empty((int(n_steps), self.num_envs, 2), dtype=torch.float32, device=self.device)
+                if return_actions else None)
+        _capi.check(self.lib.sbr_rollout(self._h, int(n_steps), C.c_uint64(int(policy_seed)), _ptr(ret), _ptr(acts),
+                                         self._stream()), self._h)
+        return (ret, acts) if return_actions else ret
+
+    # ------------------------------------------------------------------ inspection / parity injection
+    def get_state(self):
+        x = torch.empty((_capi.NX, self.num_envs), dtype=torch.float64, device=self.device)
+        ctrl = torch.empty((_capi.NCTRL, self.num_envs), dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.sbr_get_state(self._h, _ptr(x), _ptr(ctrl), self._stream()), self._h)
+        return x, ctrl
+
+    def set_state(self, x=None, ctrl=None):
+        x = self._dev(x, torch.float64, (_capi.NX, self.num_envs))
+        ctrl = self._dev(ctrl, torch.float64, (_capi.NCTRL, self.num_envs))
+        _capi.check(self.lib.sbr_set_state(self._h, _ptr(x), _ptr(ctrl), self._stream()), self._h)
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def influent(self):
+        out = torch.empty((_capi.NX, self.num_envs), dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.sbr_get_influent(self._h, _ptr(out), self._stream()), self._h)
+        return out
+
+    def status(self):
+        """Sticky domain-of-validity bits per env (int64; _capi.ST_NEGATIVE | ST_NEAR_POLE | ST_NONFINITE): the
+        reference model has no guards and can be driven to negative ammonia / a Monod pole by aggressive policies."""
+        _, ctrl = self.get_state()
+        return ctrl[_capi.C_STATUS].to(torch.int64)
+
+    def episode_returns(self):
+        _, ctrl = self.get_state()
+        return ctrl[_capi.C_RETURN]
+
+    def stats(self, values):
+        v = self._dev(values, torch.float64, (values.numel(),))
+        out = torch.empty((4,), dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.sbr_reduce_stats(self._h, _ptr(v), v.numel(), _ptr(out), self._stream()), self._h)
+        s, mn, mx, cnt = out.tolist()
+        return {"sum": s, "min": mn, "max": mx, "count": cnt, "mean": s / cnt if cnt else float("nan")}
+
+    def eval_rhs(self, kind, x, kla, ec, loading=None):
+        x = torch.as_tensor(x, dtype=torch.float64, device=self.device).contiguous()
+        n = x.shape[0]
+        kla = self._dev(kla, torch.float64, (n,))
+        ec = self._dev(ec, torch.float64, (n,))
+        ld = self._dev(loading, torch.float64, (n, _capi.NX))
+        dx = torch.empty_like(x)
+        _capi.check(self.lib.sbr_eval_rhs(self._h, int(kind), n, _ptr(x), _ptr(kla), _ptr(ec), _ptr(ld), _ptr(dx),
+                                          self._stream()), self._h)
+        return dx
+
+    def draw_normals(self, seed):
+        out = torch.empty((self.num_envs, _capi.NSAMP), dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.sbr_draw_normals(self._h, C.c_uint64(int(seed)), _ptr(out), self._stream()), self._h)
+        return out
+
+    # ------------------------------------------------------------------ device timing (bench.py)
+    def timer_start(self):
+        _capi.check(self.lib.sbr_timer_start(self._h, self._stream()), self._h)
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _capi.check(self.lib.sbr_timer_stop(self._h, self._stream(), C.byref(ms)), self._h)
+        return float(ms.value)

@@ -10,7 +10,9 @@
  * message is available from sbr_last_error().  Nothing here ever falls back to the CPU.
  *
  * Layouts
- *   action  [N][2]  float32   (u_DO set-point, u_EC set-point)   gym_SBR_oneshot.py:843,862,898
+ *   action  [N][2]  ActT      (u_DO set-point, u_EC set-point)   gym_SBR_oneshot.py:843,862,898
+ *                             ActT = float32 (cfg.act_f64 = 0) or float64 (cfg.act_f64 = 1, what the reference's
+ *                             step() receives; the NO3 loop's gain makes EC sensitive to set-point rounding)
  *   obs     [N][18] OutT      obs_DO[9] ++ obs_EC[9]             gym_SBR_oneshot.py:1027-1114
  *   state   [N][15] OutT      [t, x0..x13] / x_1_state           gym_SBR_oneshot.py:1020-1025
  *   reward  [N]     OutT                                         module_reward_EQIOCI.py:4-115
@@ -42,14 +44,26 @@ enum {
     SBR_C_T = 0,           /* running time t (days)                     gym_SBR_oneshot.py:1357 */
     SBR_C_SO_M1, SBR_C_SO_M2, SBR_C_SNO_M1, SBR_C_SNO_M2,   /* So[-1] So[-2] Sno[-1] Sno[-2]  :1959-1961 */
     SBR_C_IE_DO, SBR_C_IE_EC,                               /* PID integrals                  :1893,:1923 */
-    SBR_C_KLA_LAST, SBR_C_EC_LAST, SBR_C_EC_PREV,           /* Kla[-1], EC[-1], EC of interval before */
+    SBR_C_EC_LAST, SBR_C_EC_PREV,                           /* EC[-1] and EC of the interval before it */
     SBR_C_U_DO, SBR_C_U_EC,                                 /* set-points in force            :862-906 */
-    SBR_C_KLA_HIST0,                                        /* 10 entries, oldest first */
-    SBR_C_QW = SBR_C_KLA_HIST0 + SBR_KLA_HIST,              /* wastage flow of the last terminal step :2376 */
+    SBR_C_KLA_HIST0,                                        /* 10 entries, oldest first; the last is Kla[-1] */
+    SBR_C_KLA_LAST = SBR_C_KLA_HIST0 + SBR_KLA_HIST - 1,
+    SBR_C_QW,                                               /* wastage flow of the last terminal step :2376 */
     SBR_C_RETURN,                                           /* sum of rewards since reset */
     SBR_C_STEPS,                                            /* step() calls since reset (as double) */
-    SBR_C_DONE                                              /* 1.0 once the episode ended */
+    SBR_C_DONE,                                             /* 1.0 once the episode ended */
+    SBR_C_STATUS                                            /* sticky SBR_ST_* bits since reset (as double) */
 };
+
+/* Domain-of-validity flags.  The ASM1 rate expressions x/(K+x) have poles at x = -K and the reference has no
+ * guards (gym_SBR_oneshot.py:1660-1685): heterotrophic growth takes up ammonia without an ammonia limitation, so an
+ * aggressive policy can drive Snh (also So, Sno) below zero and towards a pole, after which the reference - and this
+ * library, which reproduces it - returns numbers without physical meaning.  The numerics are NOT altered; these
+ * bits, checked at the end of every control interval, only make the condition visible. */
+#define SBR_ST_NEGATIVE 1   /* one of Ss, Xs, Xbh, So, Sno, Snh was below -1e-6 */
+#define SBR_ST_NEAR_POLE 2  /* Ss, So, Sno or Snh came within 50 % of a Monod pole (x < -K/2): parity to 1e-5 between
+                               any two fp64 implementations holds only while this bit is clear (tests/) */
+#define SBR_ST_NONFINITE 4  /* a state component is NaN or infinite */
 
 typedef enum {
     SBR_OK = 0,
@@ -80,7 +94,8 @@ typedef struct sbr_config {
     int32_t substeps;          /* RK4 substeps per control interval (10 => h = dt) */
     int32_t out_f64;           /* 0: obs/state/reward are float32; 1: float64 */
     int32_t terminal;          /* 1: run settle/draw/idle on the done step (reference behaviour) */
-    int32_t auto_reset;        /* 0: a finished env ignores step() until sbr_reset (reference: caller resets) */
+    int32_t act_f64;           /* 0: sbr_step reads float32 actions; 1: float64.  A finished env ignores step()
+                                  until sbr_reset either way (the reference leaves resetting to the caller) */
 } sbr_config;
 
 typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for N envs on one GPU */
@@ -118,7 +133,7 @@ int sbr_reset(sbr_env* env, uint64_t seed, const int32_t* scenario, const double
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
  * one (at phase boundaries two) control interval(s) of RK4, reward, observations, and on the last
  * call of an episode the settle/draw/idle phases.  Any of obs/state/reward/done may be NULL. */
-int sbr_step(sbr_env* env, const float* action, void* obs, void* state, void* reward, uint8_t* done,
+int sbr_step(sbr_env* env, const void* action, void* obs, void* state, void* reward, uint8_t* done,
              void* stream);
 
 /* fused rollout with an on-device uniform random policy (BASELINE.json configs[4]): n_steps step()
@@ -136,6 +151,10 @@ int sbr_reduce_stats(sbr_env* env, const double* values, int64_t n, double* out4
 /* parity injection / inspection: x is [SBR_NX][N], ctrl is [SBR_NCTRL][N], float64, DEVICE pointers. */
 int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
 int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
+
+/* the flow-weighted influent each env was reset with (buffer_tank3.py:87-107; entry 0 = Qin/T_fill,
+ * gym_SBR_oneshot.py:287): out is [SBR_NX][N] float64, DEVICE pointer. */
+int sbr_get_influent(sbr_env* env, double* out, void* stream);
 
 /* standalone right-hand sides for known-answer tests (gym_SBR_oneshot.py:1658-1787, :1424-1583,
  * :2424-2552).  x [n][14], kla [n], ec [n], loading [n][14] or NULL, dx [n][14]; DEVICE pointers.

@@ -31,7 +31,7 @@ typedef struct {
     double act_DO_max, act_EC_max;
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
     double x0[NX];
-    int32_t substeps, out_f64, terminal, auto_reset;
+    int32_t substeps, out_f64, terminal, act_f64;
 } sbro_params;
 
 /* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
@@ -43,13 +43,15 @@ typedef struct {
     double kla_last, ec_last, ec_prev;
     double u_do, u_ec;
     double kla_hist[KLA_HIST];      /* oldest first; [KLA_HIST-1] is the current interval's Kla */
-    double qw, ret, steps, done;
+    double qw, ret, steps, done, status;
     double influent[NX];            /* loading vector, [0] = Qin/T_fill */
     double x_start[NX];             /* start state of the last interval (for xdot) */
     double span;                    /* t_range[-1]-t_range[0] of the last interval */
     int32_t n_rows;                 /* 9 or 10: len(t_range) of the last interval */
     int32_t n_intervals;            /* intervals run by the last step() call */
 } sbro_env;
+
+static double status_bits(const sbro_params* p, const double* x, double status);
 
 static const double X1_STATE[15] = {0.5, 1.32, 30, 30, 1500, 150, 3000, 2000, 600, 8, 20, 20, 10, 10, 10};
 
@@ -76,7 +78,7 @@ void sbro_default_params(sbro_params* p) {
                                   13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
                                   3.790463057094611};
     memcpy(p->x0, x0, sizeof x0);
-    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->auto_reset = 0;
+    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->act_f64 = 0;
 }
 
 int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }
@@ -279,6 +281,7 @@ void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, do
     for (int j = 0; j < KLA_HIST; ++j) e->kla_hist[j] = ((KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;
     e->kla_last = kla; e->ec_last = 0; e->ec_prev = 0;
     e->qw = 0; e->ret = 0; e->steps = 0; e->done = 0;
+    e->status = status_bits(p, e->x, 0);
     memcpy(e->x_start, x0c, sizeof x0c);
     e->span = t_end; e->n_rows = n_rows; e->n_intervals = 0;
     if (obs) {
@@ -287,6 +290,20 @@ void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, do
         for (int i = 0; i < NX; ++i) xr[i] = (qin * e->influent[i] + e->x[i] * p->IV) / (qin + p->IV);
         build_obs(e->t, xr, x0c, e->x, obs);
     }
+}
+
+/* sticky domain-of-validity bits, same definition as SBR_ST_* in include/sbr_amd.h (not in the reference, which
+ * has no guards: this only REPORTS that a concentration went negative / approached a pole of x/(K+x)) */
+static double status_bits(const sbro_params* p, const double* x, double status) {
+    int st = (int)status;
+    const double lo = -1e-6;
+    if (x[2] < lo || x[4] < lo || x[5] < lo || x[8] < lo || x[9] < lo || x[10] < lo) st |= 1;
+    const double ko = p->Koh < p->Koa ? p->Koh : p->Koa;
+    if (x[2] < -0.5 * p->Ks || x[8] < -0.5 * ko || x[9] < -0.5 * p->Kno || x[10] < -0.5 * p->Knh) st |= 2;
+    double sum = 0;
+    for (int i = 0; i < NX; ++i) sum += x[i];
+    if (!(fabs(sum) < 1.7e308)) st |= 4;
+    return (double)st;
 }
 
 /* ---------------------------------------------------------------------------------- interval */
@@ -317,6 +334,7 @@ static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
     e->so_m2 = e->so_m1; e->so_m1 = e->x[8];
     e->sno_m2 = e->sno_m1; e->sno_m1 = e->x[9];
     e->t = t1; e->span = t1 - t0; e->n_rows = n_rows; e->n_intervals += 1;
+    e->status = status_bits(p, e->x, e->status);
 }
 
 /* module_reward_EQIOCI.py:4-115 */
@@ -390,6 +408,8 @@ static void terminal(const sbro_params* p, sbro_env* e) {
     if (kla < p->Kla_min) { kla = p->Kla_min; e->ie_do = e->ie_do - err * p->dt; }
     const int n_rows = (int)((p->t_cycle - t_after_draw) / p->dt);
     rk4_span(p, 2, x, p->t_cycle - t_after_draw, n_rows, kla, 0, 0);
+    for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];   /* Kla.append, :2578 */
+    e->kla_hist[KLA_HIST - 1] = kla;
     e->kla_last = kla;
 }
 

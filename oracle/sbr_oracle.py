@@ -20,7 +20,7 @@ class Params(C.Structure):
         "So_sat Kla_min Kla_max Kc_DO tauI_DO tauD_DO EC_min EC_max Kc_EC tauI_EC tauD_EC EC_conc "
         "act_DO_max act_EC_max biomass_setpoint Qeff settler_area settler_vmax").split()] + [
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("auto_reset", C.c_int32)]
+        ("terminal", C.c_int32), ("act_f64", C.c_int32)]
 
 
 class Env(C.Structure):
@@ -31,14 +31,14 @@ class Env(C.Structure):
                 ("u_do", C.c_double), ("u_ec", C.c_double),
                 ("kla_hist", C.c_double * KLA_HIST),
                 ("qw", C.c_double), ("ret", C.c_double), ("steps", C.c_double), ("done", C.c_double),
-                ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
+                ("status", C.c_double), ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
                 ("n_rows", C.c_int32), ("n_intervals", C.c_int32)]
 
 
 ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "f8"), ("sno_m1", "f8"),
                       ("sno_m2", "f8"), ("ie_do", "f8"), ("ie_ec", "f8"), ("kla_last", "f8"), ("ec_last", "f8"),
                       ("ec_prev", "f8"), ("u_do", "f8"), ("u_ec", "f8"), ("kla_hist", "f8", KLA_HIST),
-                      ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("influent", "f8", NX),
+                      ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("status", "f8"), ("influent", "f8", NX),
                       ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4")], align=True)
 
 
@@ -50,12 +50,25 @@ def build(force=False):
 
 
 _lib = None
+_variant = ""          # "" = strict build (no FMA contraction); "_fma" = same source with -mfma -ffp-contract=fast
+
+
+def use_variant(suffix):
+    """Switch to another build of the SAME source (tests/test_oracle_golden.py uses "_fma" as a control for how
+    far pure rounding differences get amplified by the closed loop).  Returns the previous variant."""
+    global _lib, _variant
+    prev = _variant
+    if suffix != _variant:
+        if suffix:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libsbr_oracle%s.so" % suffix])
+        _lib, _variant = None, suffix
+    return prev
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(build() if not _variant else os.path.join(_HERE, "libsbr_oracle%s.so" % _variant))
         assert _lib.sbro_sizeof_env() == C.sizeof(Env) == ENV_DTYPE.itemsize, "oracle env layout drifted"
         assert _lib.sbro_sizeof_params() == C.sizeof(Params), "oracle params layout drifted"
     return _lib
@@ -98,6 +111,19 @@ class OracleBatch:
         for i in range(self.n):
             lib().sbro_draw_normals(C.c_uint64(seed), C.c_uint64(self.first_env_id + i), _p(out[i]))
         return out
+
+    def load_state(self, x, ctrl):
+        """Overwrite the plant/controller state from the product's layout: x [14][n], ctrl [26][n]
+        (rows as in include/sbr_amd.h).  Used to re-synchronise the oracle to the device before a call."""
+        x, ctrl = np.asarray(x, dtype=np.float64), np.asarray(ctrl, dtype=np.float64)
+        e = self.envs
+        e["x"] = x.T
+        for row, name in enumerate(["t", "so_m1", "so_m2", "sno_m1", "sno_m2", "ie_do", "ie_ec", "ec_last", "ec_prev",
+                                    "u_do", "u_ec"]):
+            e[name] = ctrl[row]
+        e["kla_hist"] = ctrl[11:21].T
+        e["kla_last"] = ctrl[20]
+        e["qw"], e["ret"], e["steps"], e["done"], e["status"] = ctrl[21], ctrl[22], ctrl[23], ctrl[24], ctrl[25]
 
     def reset(self, influent):
         influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64)

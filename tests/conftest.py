@@ -30,3 +30,25 @@ def gate(x, ref):
     from oracle import sbr_params as P
     x, ref = np.asarray(x), np.asarray(ref)
     return np.abs(x - ref) / (P.RTOL_GATE * np.abs(ref) + P.RTOL_GATE * P.STATE_SCALE)
+
+
+# (state index, normaliser) of the 18 observation entries, gym_SBR_oneshot.py:150-156 and :1069-1076;
+# index -1 = time (exact)
+OBS_SPEC = [(-1, 0.5), (5, 2000), (6, 500), (8, 8.0), (10, 10), (5, 4000), (6, 500), (8, 8), (10, 50),
+            (-1, 0.5), (2, 30), (5, 2000), (9, 10), (10, 10), (2, 50), (5, 4000), (9, 50), (10, 50)]
+
+
+def obs_tolerance(x_ref, frac=1.0):
+    """What the state gate allows in observation units: an entry is x_i/norm (or a clipped difference of
+    two states over norm), so it inherits frac * (1e-5*|x_i| + 1e-5*scale_i) / norm, twice that for the
+    difference entries (start and end state each carry the gate)."""
+    from oracle import sbr_params as P
+    x_ref = np.atleast_2d(np.asarray(x_ref, dtype=np.float64))
+    tol = np.empty((x_ref.shape[0], 18))
+    for j, (i, norm) in enumerate(OBS_SPEC):
+        if i < 0:
+            tol[:, j] = 1e-15
+        else:
+            g = P.RTOL_GATE * np.abs(x_ref[:, i]) + P.RTOL_GATE * P.STATE_SCALE[i]
+            tol[:, j] = frac * g / norm * (2.0 if j in (5, 6, 7, 8, 14, 15, 16, 17) else 1.0)
+    return tol
