@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py - batched SBROS-v1 env-steps/s on N MI355X (one process per GPU), next to the kernel's roofline and a
+CPU baseline.
+
+    python bench.py --gpus 1 --steps K --warmup W                         (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W                            (N > 1, RCCL)
+
+A "step" is one sbr_step() launch over this rank's batch: every env advances one control interval (two on the three
+phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
+    config2 (default)  65536 envs per GPU, stochastic influent (Philox normals drawn on the device), scenario = global env
+                       id mod 8, uniform random float32 set-points already resident in HBM, per-step API, RK4 h = dt.
+                       With N > 1 GPUs this is configs[3]'s shape (envs sharded by global id, one RCCL all-gather of the
+                       episode returns per episode, inside the timed region); per-GPU work is fixed => weak scaling.
+    config1            4096 envs per GPU, deterministic influent (64 wavefronts: cannot fill 1024 SIMDs; a parity case)
+    config5            65536 envs per GPU, fused on-device random-policy rollout (sbr_rollout), 463 calls per launch
+Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase) runs INSIDE the timed region and is
+not counted as steps.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
+HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+CALLS_PER_EPISODE = 463
+
+
+def cpu_baseline(n_envs=4096, calls=100):
+    """The CPU oracle (a C port of the same algorithm: RK4, fp64, OpenMP over envs) timed on this box's host cores, on a
+    bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
+    import numpy as np
+    from oracle import sbr_oracle as O
+    from gym_sbr2_amd.vec_env import load_influent_tables
+    means, stds = load_influent_tables()
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    scen = (np.arange(n_envs) % 8).astype(np.int32)
+    b = O.OracleBatch(n_envs, nthreads=cores)
+    infl = b.mix(means, stds, scen, b.normals(0))
+    rs = np.random.RandomState(0)
+    acts = [np.column_stack([rs.uniform(0, 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
+    best = 0.0
+    for _ in range(3):                 # best of three: shared hosts are noisy
+        b.reset(infl)
+        b.step(acts[0], want_obs=False)
+        t0 = time.perf_counter()
+        for a in acts:
+            b.step(a, want_obs=True)
+        best = max(best, n_envs * calls / (time.perf_counter() - t0))
+    return {"value": best, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d step() calls of the same workload, oracle/sbr_oracle.c with %d OpenMP threads, best of 3"
+                      % (n_envs, calls, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1852)       # four episodes
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config5"])
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gym_sbr2_amd import SbrOSVec, _capi
+    from gym_sbr2_amd.sharding import gather_returns
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
+
+    n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
+    n_global = n_local * world
+    first = rank * n_local
+    env = SbrOSVec(n_local, device=local_rank, first_env_id=first, out_dtype=torch.float32)
+    gid = torch.arange(first, first + n_local, device=dev)
+    scenario = (gid % 8).to(torch.int32)
+    rnd0 = torch.zeros(n_local, 48, dtype=torch.float64, device=dev) if args.workload == "config1" else None
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    pool = torch.rand(64, n_local, 2, device=dev, generator=gen) * torch.tensor([8.0, 15.0], device=dev)   # resident actions
+    fused = args.workload == "config5"
+    state = {"episode": 0, "in_episode": 0, "returns": None}
+    seg_events = []
+
+    def reset():
+        env.reset(seed=1000 + state["episode"], scenario=scenario, rnd=rnd0)
+        state["episode"] += 1
+        state["in_episode"] = 0
+
+    def end_of_episode():
+        ret = env.episode_returns().to(torch.float32)
+        state["returns"] = gather_returns(ret, n_global) if world > 1 else ret      # configs[3]: the one collective
+
+    def run(k_steps, record):
+        done = 0
+        while done < k_steps:
+            if state["in_episode"] == CALLS_PER_EPISODE:
+                end_of_episode()
+                reset()
+            m = min(k_steps - done, CALLS_PER_EPISODE - state["in_episode"])
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if fused:
+                env.rollout(m, policy_seed=77)
+            else:
+                for j in range(m):
+                    env.step(pool[(state["in_episode"] + j) & 63])
+            if record:
+                e1.record()
+                seg_events.append((e0, e1, m))
+            state["in_episode"] += m
+            done += m
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    reset()
+    run(args.warmup, record=False)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, record=True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: device time of the step launches of the timed region, from events on the launch stream
+    dev_ms = sum(a.elapsed_time(b) for a, b, _ in seg_events)
+    launches = sum(m for _, _, m in seg_events) if not fused else len(seg_events)
+    per_launch_s = dev_ms * 1e-3 / max(launches, 1)
+    calls_per_launch = 1 if not fused else args.steps / max(len(seg_events), 1)
+    achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
+    status = env.status()
+    out = {
+        "metric": "env-steps/sec (batched)",
+        "value": n_global * args.steps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": {"config1": "configs[1]: 4096 envs/GPU, fixed-step RK4 (10 substeps), deterministic influent, per-step API",
+                                "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, fixed-step RK4 (10 substeps), "
+                                           "per-step API" + ("; sharded over %d GPUs with one RCCL all-gather of episode returns per "
+                                                             "episode (configs[3] shape)" % world if world > 1 else ""),
+                                "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload],
+                   "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
+                   "resets_in_timed_region": max(state["episode"] - 1, 0), "actions": "uniform random set-points, float32, resident in HBM",
+                   "kernel": "k_rollout" if fused else "k_step<float,float,%d>" % (2 if n_local > 98304 else 1)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                     "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
+                     "note": "fp64 VALU-bound, not HBM-bound: ~5.7 kFLOP per env-step at ~11 FLOP/B (SURVEY.md 8d); see DESIGN.md"},
+        "env_status": {"near_pole_frac": float(((status & _capi.ST_NEAR_POLE) != 0).float().mean().item()),
+                       "nonfinite": int(((status & _capi.ST_NONFINITE) != 0).sum().item())},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    """In-tree libsbr_amd.so; SBR_AMD_LIB overrides it (kernel A/B experiments only, scripts/gpu_ab.py)."""
+    return os.environ.get("SBR_AMD_LIB") or _build.LIB
 
 
 def load(build_if_missing=True):
@@ -71,7 +72,9 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = library_path()
-    if not os.path.exists(path) or (_build.is_stale() and build_if_missing):
+    if path != _build.LIB:
+        build_if_missing = False
+    if not os.path.exists(path) or (build_if_missing and _build.is_stale()):
         if not build_if_missing:
             raise SbrError("libsbr_amd.so is missing (%s); run python -c 'import __graft_entry__ as g; g.build()'" % path)
         _build.build_library()

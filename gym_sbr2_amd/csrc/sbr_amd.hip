@@ -20,6 +20,7 @@
 #include "sbr_device.h"
 
 #define SBR_BLOCK 64
+#define SBR_RESET_BLOCK 256     // k_reset stages 84 KiB of tables in LDS: one block per CU, so make it four waves
 static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB
 
 // ------------------------------------------------------------------------------------------- state I/O
@@ -40,46 +41,51 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i, const double (&x)[SBR_NX]) {
     for (int j = 0; j < SBR_NX; ++j) b.x[(int64_t)j * b.n + i] = x[j];
 }
 #define CTRL(f) b.ctrl[(int64_t)(f) * b.n + i]
-SBR_DEV void load_ctl(const SbrBuf& b, int64_t i, SbrCtl& c) {
-    c.t = CTRL(SBR_C_T); c.so_m1 = CTRL(SBR_C_SO_M1); c.so_m2 = CTRL(SBR_C_SO_M2);
-    c.sno_m1 = CTRL(SBR_C_SNO_M1); c.sno_m2 = CTRL(SBR_C_SNO_M2);
+// Rows the step consumes BEFORE the integration.  ec_prev, u_do, u_ec are always overwritten before use
+// (sbr_interval / sbr_run_intervals) and So[-2], Sno[-2] only feed the derivative term, so they are read only if tauD != 0.
+SBR_DEV void load_ctl_pre(const SbrPar& p, const SbrBuf& b, int64_t i, SbrCtl& c) {
+    c.t = CTRL(SBR_C_T); c.so_m1 = CTRL(SBR_C_SO_M1); c.sno_m1 = CTRL(SBR_C_SNO_M1);
     c.ie_do = CTRL(SBR_C_IE_DO); c.ie_ec = CTRL(SBR_C_IE_EC);
-    c.ec_last = CTRL(SBR_C_EC_LAST); c.ec_prev = CTRL(SBR_C_EC_PREV);
-    c.u_do = CTRL(SBR_C_U_DO); c.u_ec = CTRL(SBR_C_U_EC);
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) c.kh[j] = CTRL(SBR_C_KLA_HIST0 + j);
-    c.qw = CTRL(SBR_C_QW); c.ret = CTRL(SBR_C_RETURN); c.steps = CTRL(SBR_C_STEPS); c.done = CTRL(SBR_C_DONE);
-    c.status = CTRL(SBR_C_STATUS);
-    c.span = 0.0; c.rows = 9;
+    c.ec_last = CTRL(SBR_C_EC_LAST); c.kla_last = CTRL(SBR_C_KLA_LAST);
+    const bool deriv = (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0);            // wave-uniform
+    c.so_m2 = deriv ? CTRL(SBR_C_SO_M2) : c.so_m1;
+    c.sno_m2 = deriv ? CTRL(SBR_C_SNO_M2) : c.sno_m1;
+    c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
 }
-SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c) {
+// Rows needed only AFTER the integration: the nine older Kla values (hist[9] = Kla[-1] was loaded before).
+SBR_DEV void load_hist(const SbrBuf& b, int64_t i, double kla_last_before, double (&hist)[SBR_KLA_HIST]) {
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = CTRL(SBR_C_KLA_HIST0 + j);
+    hist[SBR_KLA_HIST - 1] = kla_last_before;
+}
+SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], double ret,
+                       double steps, double status) {
     CTRL(SBR_C_T) = c.t; CTRL(SBR_C_SO_M1) = c.so_m1; CTRL(SBR_C_SO_M2) = c.so_m2;
     CTRL(SBR_C_SNO_M1) = c.sno_m1; CTRL(SBR_C_SNO_M2) = c.sno_m2;
     CTRL(SBR_C_IE_DO) = c.ie_do; CTRL(SBR_C_IE_EC) = c.ie_ec;
     CTRL(SBR_C_EC_LAST) = c.ec_last; CTRL(SBR_C_EC_PREV) = c.ec_prev;
     CTRL(SBR_C_U_DO) = c.u_do; CTRL(SBR_C_U_EC) = c.u_ec;
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(SBR_C_KLA_HIST0 + j) = c.kh[j];
-    CTRL(SBR_C_QW) = c.qw; CTRL(SBR_C_RETURN) = c.ret; CTRL(SBR_C_STEPS) = c.steps; CTRL(SBR_C_DONE) = c.done;
-    CTRL(SBR_C_STATUS) = c.status;
+    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(SBR_C_KLA_HIST0 + j) = hist[j];
+    CTRL(SBR_C_RETURN) = ret; CTRL(SBR_C_STEPS) = steps; CTRL(SBR_C_STATUS) = status;
 }
-#undef CTRL
 
 // ------------------------------------------------------------------------------------------- reset
 // SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
 // workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
 template <typename OutT>
-__global__ __launch_bounds__(SBR_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
+__global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
                                                     uint64_t seed, const int32_t* __restrict__ scenario,
                                                     const double* __restrict__ rnd, const double* __restrict__ influent,
                                                     const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][14][48]
     const bool need_tables = (influent == nullptr);
     if (need_tables) {
-        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_BLOCK) lds[k] = tables[k];
+        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
         __syncthreads();
     }
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
     if (i >= b.n) return;
     if (mask != nullptr && mask[i] == 0) return;
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_reset(SbrPar p, SbrBuf b, const d
 #pragma unroll
     for (int j = 0; j < SBR_NX; ++j) { x[j] = p.x0[j]; x0[j] = p.x0[j]; }
     SbrCtl c;
+    double hist[SBR_KLA_HIST];
     const double e = 0.0 - x0[8];
     double ie = 0.0;
     double kla = p.Kc_DO * e + p.KcI_DO * ie;
@@ -135,47 +142,74 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_reset(SbrPar p, SbrBuf b, const d
     c.ie_do = ie; c.ie_ec = 0.0; c.ec_last = 0.0; c.ec_prev = 0.0;
     c.u_do = 0.0; c.u_ec = 15.0;                                     // :212-213
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) c.kh[j] = ((SBR_KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;   // [0,k]*126, :323
-    c.qw = 0.0; c.ret = 0.0; c.steps = 0.0; c.done = 0.0;
-    c.status = sbr_status_bits(p, x, 0.0);
+    for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = ((SBR_KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;   // [0,k]*126, :323
+    c.kla_last = kla;
     store_x(b, i, x);
-    store_ctl(b, i, c);
+    store_ctl(b, i, c, hist, 0.0, 0.0, (double)sbr_status_bits(p, x));
+    CTRL(SBR_C_QW) = 0.0; CTRL(SBR_C_DONE) = 0.0;
     if (obs) {   // volume blend of influent and post-fill state, :346-361
         double xr[SBR_NX];
 #pragma unroll
         for (int j = 0; j < SBR_NX; ++j) xr[j] = (p.qin * ld[j] + x[j] * p.IV) / (p.qin + p.IV);
-        sbr_write_obs<OutT>(obs + i * SBR_NOBS, c.t, xr, x0, x);
+        double x06[SBR_NXD];
+        sbr_take6(x0, x06);
+        sbr_write_obs<OutT>(obs + i * SBR_NOBS, 1, c.t, xr, x06, x);
     }
 }
 
 // ------------------------------------------------------------------------------------------- step
-template <typename OutT, typename ActT>
-__global__ __launch_bounds__(SBR_BLOCK) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
-                                                   OutT* __restrict__ obs, OutT* __restrict__ state,
-                                                   OutT* __restrict__ reward, uint8_t* __restrict__ done) {
+// All loads of a lane are issued up front (they are asynchronous; the first use waits): one exposed memory round
+// trip per launch.  Measured alternatives that were WORSE (profiles/r01_notes.md): loading the Kla history and the
+// bookkeeping rows after the integration (+2.4 us: three serial round trips), and staging obs/state through LDS for
+// coalesced stores (no gain: L2 write-combining already absorbs the 72/60-byte rows).
+// Two builds of the kernel: W = 1 lets the allocator use the whole register file (fastest single wave: batches of up
+// to one wave per SIMD, N <= 65536) and W = 2 keeps two waves resident per SIMD so that the load/store phases of one
+// overlap the arithmetic of the other (measured on MI355X: -4 % at N = 65536, +7 % at 131072, +18 % at 262144).
+// Values that only have to SURVIVE the integration (Kla history, return/steps/status, the xdot start values: 19
+// doubles per lane) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip
+// through L2/HBM, and the RK4 loop keeps its registers.  Slot j of lane l is at park[j*64 + l] (conflict-free).
+#define SBR_NPARK (SBR_KLA_HIST - 1 + 4 + SBR_NXD)
+template <typename OutT, typename ActT, int W>
+__global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
+                                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
+                                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
+    __shared__ double park[SBR_NPARK * SBR_BLOCK];
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= b.n) return;
-    double x[SBR_NX], xa[SBR_NX];
+    double* my = park + threadIdx.x;
+    double x[SBR_NX];
     SbrCtl c;
     load_x(b, i, x);
-    load_ctl(b, i, c);
-    if (c.done != 0.0) {          // finished env: waits for sbr_reset (the reference leaves resetting to the caller)
-        if (reward) reward[i] = (OutT)0;
-        if (done) done[i] = 1;
-        if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, p.t_cycle, x, x, x);
-        if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, p.t_cycle, x);
-        return;
-    }
+    load_ctl_pre(p, b, i, c);
+    const double kla_before = c.kla_last;
+    const double done0 = CTRL(SBR_C_DONE);
     const double a0 = (double)action[2 * i], a1 = (double)action[2 * i + 1];     // one 8- or 16-byte load per lane
-    double t_obs;
-    bool dn;
-    const double r = sbr_step_env(p, c, x, a0, a1, xa, t_obs, dn);
-    store_x(b, i, x);
-    store_ctl(b, i, c);
-    if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, t_obs, x, xa, x);
-    if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, t_obs, x);
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * 64] = CTRL(SBR_C_KLA_HIST0 + j);
+    my[9 * 64] = CTRL(SBR_C_RETURN); my[10 * 64] = CTRL(SBR_C_STEPS); my[11 * 64] = CTRL(SBR_C_STATUS);
+    SbrX6Lds x6{my + 13 * 64};
+    x6.put(x);
+    double t_obs = p.t_cycle, r = 0.0;
+    bool dn = true;
+    double xa6[SBR_NXD];
+    if (done0 == 0.0) {                   // a finished env waits for sbr_reset (the reference leaves resetting to the caller)
+        double qw = 0.0, hist[SBR_KLA_HIST];
+        sbr_run_intervals(p, c, x, a0, a1, x6);
+#pragma unroll
+        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * 64];
+        hist[SBR_KLA_HIST - 1] = kla_before;
+        x6.get(xa6);
+        r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
+        store_x(b, i, x);
+        store_ctl(b, i, c, hist, my[9 * 64] + r, my[10 * 64] + 1.0, (double)((int)my[11 * 64] | c.st_new));
+        if (dn) { CTRL(SBR_C_DONE) = 1.0; if (p.terminal) CTRL(SBR_C_QW) = qw; }
+    } else {
+        x6.get(xa6);
+    }
     if (reward) reward[i] = (OutT)r;
     if (done) done[i] = dn ? 1 : 0;
+    if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, 1, t_obs, x, xa6, x);
+    if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, 1, t_obs, x);
 }
 
 // ------------------------------------------------------------------------------------------- rollout
@@ -184,24 +218,36 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= b.n) return;
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
-    double x[SBR_NX], xa[SBR_NX];
+    double x[SBR_NX], xa6[SBR_NXD], hist[SBR_KLA_HIST];
     SbrCtl c;
+    SbrX6Reg x6;
     load_x(b, i, x);
-    load_ctl(b, i, c);
+    load_ctl_pre(p, b, i, c);
+    load_hist(b, i, c.kla_last, hist);
+    double ret = CTRL(SBR_C_RETURN), steps = CTRL(SBR_C_STEPS), done_f = CTRL(SBR_C_DONE), qw = CTRL(SBR_C_QW);
+    int status = (int)CTRL(SBR_C_STATUS);
+    c.ec_prev = CTRL(SBR_C_EC_PREV); c.u_do = CTRL(SBR_C_U_DO); c.u_ec = CTRL(SBR_C_U_EC);   // kept if nothing runs
+    c.so_m2 = CTRL(SBR_C_SO_M2); c.sno_m2 = CTRL(SBR_C_SNO_M2);
     double acc = 0.0;
     for (int32_t s = 0; s < n_steps; ++s) {
         float a0, a1;
-        sbr_policy_action(p, policy_seed, gid, (uint32_t)c.steps, a0, a1);
+        sbr_policy_action(p, policy_seed, gid, (uint32_t)steps, a0, a1);
         if (actions_out) reinterpret_cast<float2*>(actions_out)[(int64_t)s * b.n + i] = make_float2(a0, a1);
-        if (c.done != 0.0) continue;
+        if (done_f != 0.0) continue;
         double t_obs;
         bool dn;
-        acc += sbr_step_env(p, c, x, (double)a0, (double)a1, xa, t_obs, dn);
+        sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
+        x6.get(xa6);
+        const double r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
+        acc += r; ret += r; steps += 1.0; status |= c.st_new;
+        if (dn) done_f = 1.0;
     }
     store_x(b, i, x);
-    store_ctl(b, i, c);
+    store_ctl(b, i, c, hist, ret, steps, (double)status);
+    CTRL(SBR_C_DONE) = done_f; CTRL(SBR_C_QW) = qw;
     if (returns) returns[i] = acc;
 }
+#undef CTRL
 
 // ------------------------------------------------------------------------------------------- stats
 // {sum, min, max, count} of a per-env vector: butterfly over the 64 lanes of each wave (DPP/swizzle via
@@ -329,6 +375,7 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.biomass_setpoint = c.biomass_setpoint; p.Qeff = c.Qeff; p.settler_area = c.settler_area;
     p.settler_vmax = c.settler_vmax;
     memcpy(p.x0, c.x0, sizeof p.x0);
+    p.muH_etag = c.muH * c.eta_g;
     p.substeps = c.substeps; p.terminal = c.terminal;
     p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
     p.pad_ = 0;
@@ -337,8 +384,13 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                         hipStream_t st) {
-    hipLaunchKernelGGL((k_step<OutT, ActT>), dim3((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK)), dim3(SBR_BLOCK), 0, st,
-                       e->par, e->buf, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+    const dim3 grid((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK));
+    if (e->n > 98304)      // more than 1.5 waves per SIMD on 1024 SIMDs: the two-waves-per-SIMD build wins
+        hipLaunchKernelGGL((k_step<OutT, ActT, 2>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
+                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+    else
+        hipLaunchKernelGGL((k_step<OutT, ActT, 1>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
+                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
 }
 
 extern "C" {
@@ -395,6 +447,10 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
         if (rows != 10) bad = "t_delta must be 10*dt (the reward's Kla look-back is 9 intervals)";
     }
     if (!(c.T_fill > 0) || (int)(c.T_fill / c.dt) < 1) bad = "T_fill/dt must be >= 1";
+    // every reaction phase must be longer than one control interval, so that a call runs at most two intervals
+    // (the reference's schedule: phases of 46, 190, 171 and 1 intervals; the last phase is open-ended)
+    if (!(c.T3_0 - c.T_fill > c.t_delta) || !(c.T3_end - c.T3_0 > c.t_delta) || !(c.T4_end - c.T3_end > c.t_delta))
+        bad = "phases 2, 3 and 4 must each be longer than t_delta";
     if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0)) bad = "tauI must be non-zero";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }
     derive_params(c, e->par);
@@ -476,10 +532,10 @@ int sbr_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* 
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
     if (e->cfg.out_f64)
-        hipLaunchKernelGGL(k_reset<double>, grid_for(e->n), dim3(SBR_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
+        hipLaunchKernelGGL(k_reset<double>, dim3((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), dim3(SBR_RESET_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
                            scenario, rnd, influent, mask, (double*)obs);
     else
-        hipLaunchKernelGGL(k_reset<float>, grid_for(e->n), dim3(SBR_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
+        hipLaunchKernelGGL(k_reset<float>, dim3((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), dim3(SBR_RESET_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
                            scenario, rnd, influent, mask, (float*)obs);
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;

@@ -48,40 +48,59 @@ struct SbrPar {
     // terminal
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
     double x0[SBR_NX];
+    double muH_etag;     // muH * eta_g
     int32_t substeps, terminal, fill_rows, pad_;
 };
 
 // ---------------------------------------------------------------------------------------------------
+// 1/d for the Monod denominators: v_rcp_f64 seed + two Newton steps (error <= ~1 ulp).  This is the core of LLVM's own
+// f64 division lowering without the v_div_scale / v_div_fmas / v_div_fixup range handling, which the denominators
+// here (K + x, O(0.1 .. 3000)) do not need: 5 instructions instead of ~12, and a shorter dependent chain.
+SBR_DEV double sbr_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // Conversion rates r[i] of the 11 reacting components (Si, Xi and V do not react), incl. aeration.
-// Process rates :1660-1685, combination :1731-1755.  Same association order as the reference; FMA
-// contraction by the compiler is allowed (parity is to tolerance, not bitwise).
+// Process rates :1660-1685, combination :1731-1755.  The reference's ten quotients are evaluated with SEVEN shared
+// reciprocals: So/(Koh+So) and Koh/(Koh+So) share one, and (Xs/Xbh)/(Kx + Xs/Xbh) is written Xs/(Kx*Xbh + Xs).
+// Equal coefficients are factored (nu2_1 = nu2_2, nu4_4 = nu4_5, ...).  Parity is to tolerance, not bitwise.
 SBR_DEV void sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double kla, double (&r)[SBR_NX]) {
     const double ss = x[2], xs = x[4], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10], snd = x[11],
                  xnd = x[12];
-    const double m_ss = ss / (p.Ks + ss);
-    const double m_so = so / (p.Koh + so);
-    const double i_so = p.Koh / (so + p.Koh);
-    const double m_no = sno / (p.Kno + sno);
-    const double rho1 = p.muH * m_ss * m_so * xbh;
-    const double rho2 = p.muH * m_ss * i_so * m_no * p.eta_g * xbh;
-    const double rho3 = p.muA * (snh / (p.Knh + snh)) * (so / (p.Koa + so)) * xba;
+    const double ra = sbr_rcp(p.Ks + ss);
+    const double rb = sbr_rcp(p.Koh + so);
+    const double rc = sbr_rcp(p.Kno + sno);
+    const double rd = sbr_rcp(p.Knh + snh);
+    const double re = sbr_rcp(p.Koa + so);
+    const double rf = sbr_rcp(__builtin_fma(p.Kx, xbh, xs));
+    const double rg = sbr_rcp(xs);
+    const double m_so = so * rb;                     // So/(Koh+So)
+    const double inox = (p.Koh * rb) * (sno * rc);   // Koh/(Koh+So) * Sno/(Kno+Sno)
+    const double g = (ss * ra) * xbh;                // Ss/(Ks+Ss) * Xbh
+    const double rho1 = p.muH * g * m_so;
+    const double rho2 = p.muH_etag * g * inox;
+    const double rho3 = p.muA * (snh * rd) * (so * re) * xba;
     const double rho4 = p.bH * xbh;
     const double rho5 = p.bA * xba;
     const double rho6 = p.ka * snd * xbh;
-    const double ratio = xs / xbh;
-    const double rho7 = p.kh * (ratio / (p.Kx + ratio)) * (m_so + p.eta_h * i_so * m_no) * xbh;
-    const double rho8 = (xnd / xs) * rho7;
+    const double rho7 = p.kh * (xs * rf) * __builtin_fma(p.eta_h, inox, m_so) * xbh;
+    const double rho8 = (xnd * rg) * rho7;
+    const double s12 = rho1 + rho2, s45 = rho4 + rho5;
     r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
-    r[2] = p.n2_12 * rho1 + p.n2_12 * rho2 + rho7;
-    r[4] = p.n4_45 * rho4 + p.n4_45 * rho5 - rho7;
-    r[5] = rho1 + rho2 - rho4;
+    r[2] = __builtin_fma(p.n2_12, s12, rho7);
+    r[4] = __builtin_fma(p.n4_45, s45, -rho7);
+    r[5] = s12 - rho4;
     r[6] = rho3 - rho5;
-    r[7] = p.n7_45 * rho4 + p.n7_45 * rho5;
+    r[7] = p.n7_45 * s45;
     r[8] = p.n8_1 * rho1 + p.n8_3 * rho3 + kla * (p.So_sat - so);
     r[9] = p.n9_2 * rho2 + p.n9_3 * rho3;
-    r[10] = p.n10_12 * rho1 + p.n10_12 * rho2 + p.n10_3 * rho3 + rho6;
+    r[10] = p.n10_12 * s12 + p.n10_3 * rho3 + rho6;
     r[11] = rho8 - rho6;
-    r[12] = p.n12_45 * rho4 + p.n12_45 * rho5 - rho8;
+    r[12] = __builtin_fma(p.n12_45, s45, -rho8);
     r[13] = p.n13_1 * rho1 + p.n13_2 * rho2 + p.n13_3 * rho3 + p.n13_6 * rho6;
 }
 
@@ -95,12 +114,12 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
     double r[SBR_NX];
     sbr_conversion(p, x, kla, r);
     if (KIND == 0) {
-        const double q = ec / x[0];
+        const double q = ec * sbr_rcp(x[0]);
         d[0] = ec;
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (i == 2 ? (p.EC_conc - x[i]) : (-x[i]));
     } else if (KIND == 1) {
-        const double q = ld[0] / x[0];
+        const double q = ld[0] * sbr_rcp(x[0]);
         d[0] = ld[0];
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (ld[i] - x[i]);
@@ -135,20 +154,50 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double span, int n, d
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-env controller / bookkeeping registers (mirrors the ctrl rows of sbr_amd.h)
+// Per-env controller registers that are live ACROSS the RK4 loop - kept small on purpose.  The Kla history and
+// the bookkeeping rows (return, steps, status) are not needed until after the integration, so the step kernel
+// loads them afterwards: fewer live VGPRs in the hot loop and the loads overlap nothing worse than before.
 struct SbrCtl {
     double t, so_m1, so_m2, sno_m1, sno_m2, ie_do, ie_ec, ec_last, ec_prev, u_do, u_ec;
-    double kh[SBR_KLA_HIST];   // Kla history, oldest first; kh[9] = Kla[-1]
-    double qw, ret, steps, done, status;
-    // of the last interval (not stored): span = t_range[-1]-t_range[0], rows = len(t_range) (9 or 10)
-    double span;
-    int rows;
+    double kla_last;          // Kla[-1]: bias of the velocity-form DO-PID
+    double knew[2];           // Kla values appended by this call: 1, or 2 on a phase-boundary call (sbr_create checks
+                              // that every phase is longer than t_delta, so a third interval cannot fire)
+    int n_new;
+    int st_new;               // SBR_ST_* bits raised by this call
+    double span;              // t_range[-1] - t_range[0] of the last interval
+    int rows;                 // len(t_range) of the last interval: 9 or 10
+};
+
+// the six components whose change over the (last) interval the observation reports (:1069-1076)
+#define SBR_NXD 6
+SBR_DEV void sbr_take6(const double (&x)[SBR_NX], double (&x6)[SBR_NXD]) {
+    x6[0] = x[2]; x6[1] = x[5]; x6[2] = x[6]; x6[3] = x[8]; x6[4] = x[9]; x6[5] = x[10];
+}
+// where the start values of an interval are parked while the RK4 loop runs: registers, or this lane's LDS slots
+struct SbrX6Reg {
+    double v[SBR_NXD];
+    SBR_DEV void put(const double (&x)[SBR_NX]) { sbr_take6(x, v); }
+    SBR_DEV void get(double (&o)[SBR_NXD]) const {
+#pragma unroll
+        for (int j = 0; j < SBR_NXD; ++j) o[j] = v[j];
+    }
+};
+struct SbrX6Lds {          // slot j of lane l lives at base[j * 64 + l]: conflict-free, 8-byte accesses
+    double* base;
+    SBR_DEV void put(const double (&x)[SBR_NX]) {
+        base[0 * 64] = x[2]; base[1 * 64] = x[5]; base[2 * 64] = x[6]; base[3 * 64] = x[8]; base[4 * 64] = x[9];
+        base[5 * 64] = x[10];
+    }
+    SBR_DEV void get(double (&o)[SBR_NXD]) const {
+#pragma unroll
+        for (int j = 0; j < SBR_NXD; ++j) o[j] = base[j * 64];
+    }
 };
 
 // Sticky domain-of-validity bits (SBR_ST_* in sbr_amd.h), evaluated on the end state of an interval.  x < -K/2 is
 // "within 50 % of the pole of x/(K+x)".  Pure bookkeeping: nothing in the dynamics reads it.
-SBR_DEV double sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX], double status) {
-    int st = (int)status;
+SBR_DEV int sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX]) {
+    int st = 0;
     const double lo = -1e-6;
     if (x[2] < lo || x[4] < lo || x[5] < lo || x[8] < lo || x[9] < lo || x[10] < lo) st |= SBR_ST_NEGATIVE;
     const double ko = p.Koh < p.Koa ? p.Koh : p.Koa;
@@ -157,12 +206,13 @@ SBR_DEV double sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX], doubl
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) sum += x[i];
     if (!(fabs(sum) < 1.7e308)) st |= SBR_ST_NONFINITE;          // NaN or inf anywhere
-    return (double)st;
+    return st;
 }
 
 // One control interval: Sim_aero_rxn :1877-1963 / Sim_anaero_rxn :1965-2051, run_*_step :1331-1419.
-// xs receives the interval's start state (for xdot).
-SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double (&xs)[SBR_NX], bool aerobic) {
+// xs6 receives the interval's start values of the xdot components.
+template <typename X6>
+SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& xs6, bool aerobic) {
     const double t0 = c.t, t1 = t0 + p.t_delta;
     const double span = t1 - t0;
     c.rows = (int)(span / p.dt);              // 9 or 10: fp rounding of (t+t_delta)-t   (:1339, :1384)
@@ -172,7 +222,7 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], doubl
     const double e = (aerobic ? c.u_do : 0.0) - c.so_m1;
     const double dcv = (c.so_m1 - c.so_m2) / p.dt;
     c.ie_do = c.ie_do + e * p.dt;
-    double kla = aerobic ? (p.Kc_DO * e + p.KcI_DO * c.ie_do + p.KcD_DO * dcv + c.kh[SBR_KLA_HIST - 1]) : 0.0;
+    double kla = aerobic ? (p.Kc_DO * e + p.KcI_DO * c.ie_do + p.KcD_DO * dcv + c.kla_last) : 0.0;
     if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - e * p.dt; }
     if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - e * p.dt; }
     // NO3-PID -> EC (error sign reversed, :2006); forced to 0 in aerobic intervals while its integral winds (:1918-1937)
@@ -182,26 +232,62 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], doubl
     double ec = aerobic ? 0.0 : (p.Kc_EC * e2 + p.KcI_EC * c.ie_ec + p.KcD_EC * dcv2 + c.ec_last);
     if (ec < p.EC_min) { ec = p.EC_min; c.ie_ec = c.ie_ec - e2 * p.dt; }
     else if (ec > p.EC_max) { ec = p.EC_max; c.ie_ec = c.ie_ec - e2 * p.dt; }
-#pragma unroll
-    for (int i = 0; i < SBR_NX; ++i) xs[i] = x[i];
+    xs6.put(x);
     // wave-uniform choice: if no lane doses, V/Si/Xi are constants of the interval
-    const double (&nold)[SBR_NX] = xs;
+    double nold[SBR_NX];
+#pragma unroll
+    for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
     if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<3>(p, x, span, p.substeps, kla, 0.0, nold);
     else sbr_rk4<0>(p, x, span, p.substeps, kla, ec, nold);
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) c.kh[j] = c.kh[j + 1];
-    c.kh[SBR_KLA_HIST - 1] = kla;
+    if (c.n_new == 0) c.knew[0] = kla; else c.knew[1] = kla;      // n_new <= 2, see SbrCtl
+    c.n_new += 1;
+    c.kla_last = kla;
     c.ec_prev = c.ec_last; c.ec_last = ec;
     c.so_m2 = c.so_m1; c.so_m1 = x[8];
     c.sno_m2 = c.sno_m1; c.sno_m1 = x[9];
     c.t = t1; c.span = span;
-    c.status = sbr_status_bits(p, x, c.status);
+    c.st_new |= sbr_status_bits(p, x);
+}
+
+// The phase logic of SbrOS.step (:860-1010): four sequential tests on the running time (:860, :896, :931, :963); a call
+// that crosses a phase boundary runs a second interval.  Written as a loop over the four tests so that the interval
+// code exists ONCE in the kernel.  Envs reset together are in lockstep, so the branch is wave-uniform in practice;
+// divergent waves are still correct.
+template <typename X6>
+SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6) {
+    a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
+    a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
+    c.n_new = 0; c.st_new = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const double t = c.t;
+        const bool aerobic = (pass & 1) != 0;
+        const bool fire = pass == 0 ? (t < p.T3_0)
+                        : pass == 1 ? (t >= p.T3_0 && t <= p.T3_end)
+                        : pass == 2 ? (t > p.T3_end && t <= p.T4_end)
+                                    : (t > p.T4_end);
+        if (fire && c.n_new < 2) {
+            if (aerobic) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
+            sbr_interval(p, c, x, xs6, aerobic);
+        }
+    }
+}
+
+// Kla list bookkeeping: hist is oldest-first, hist[9] = Kla[-1].
+SBR_DEV void sbr_hist_push(double (&hist)[SBR_KLA_HIST], double k) {
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = hist[j + 1];
+    hist[SBR_KLA_HIST - 1] = k;
+}
+SBR_DEV void sbr_hist_apply(const SbrCtl& c, double (&hist)[SBR_KLA_HIST]) {
+    if (c.n_new > 0) sbr_hist_push(hist, c.knew[0]);
+    if (c.n_new > 1) sbr_hist_push(hist, c.knew[1]);
 }
 
 // module_reward_EQIOCI.py:4-115.  Kla got one append per interval, EC got rows-1:  Kla[-rows:-1] is
 // the rows-1 values BEFORE the current one, EC[-rows:-1] = last value of the previous interval +
 // (rows-2) x current.
-SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&x)[SBR_NX]) {
+SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], const double (&x)[SBR_NX]) {
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
     const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
     const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
@@ -210,9 +296,9 @@ SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&x)[SB
     const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
     const double eqi2 = eqi / 10;
     const double td = 0.002 / 24;
-    double ksum = (c.rows >= 10) ? c.kh[0] : 0.0;          // 9 previous values if rows == 10, else 8
+    double ksum = (c.rows >= 10) ? hist[0] : 0.0;          // 9 previous values if rows == 10, else 8
 #pragma unroll
-    for (int j = 1; j < SBR_KLA_HIST - 1; ++j) ksum = ksum + c.kh[j];
+    for (int j = 1; j < SBR_KLA_HIST - 1; ++j) ksum = ksum + hist[j];
     const double ae = 8 / (c.span * 1.8 * 1000) * (1.32 * ksum * td);
     double esum = c.ec_prev;
     for (int j = 0; j < c.rows - 2; ++j) esum = esum + c.ec_last;
@@ -223,36 +309,38 @@ SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&x)[SB
 
 SBR_DEV double sbr_clip1(double v) { return v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v); }
 
-// obs_DO ++ obs_EC :1027-1114 (normalisers :150-156, xdot scales :1069-1076).  xr: what is reported,
-// xa -> xb: span of the clipped state change.
+// obs_DO ++ obs_EC :1027-1114 (normalisers :150-156, xdot scales :1069-1076) and state = [t, x] / x_1_state
+// (:153, :1020-1025), 33 values, written to `o` with stride `st` (the step kernel passes its LDS staging tile).
+// xr: what is reported; xa6 -> xr: span of the clipped state change.  Divisions by the constant normalisers are
+// multiplications by their reciprocals (<= 1 ulp in fp64, invisible after the float32 cast).
 template <typename OutT>
-SBR_DEV void sbr_write_obs(OutT* __restrict__ o, double t_obs, const double (&xr)[SBR_NX], const double (&xa)[SBR_NX],
+SBR_DEV void sbr_write_obs(OutT* o, int st, double t_obs, const double (&xr)[SBR_NX], const double (&xa6)[SBR_NXD],
                            const double (&xb)[SBR_NX]) {
-    const double tt = t_obs / 0.5;
-    const double dxh = sbr_clip1((xb[5] - xa[5]) / 4000), dsnh = sbr_clip1((xb[10] - xa[10]) / 50);
-    o[0] = (OutT)tt; o[1] = (OutT)(xr[5] / 2000); o[2] = (OutT)(xr[6] / 500); o[3] = (OutT)(xr[8] / 8.0);
-    o[4] = (OutT)(xr[10] / 10);
-    o[5] = (OutT)dxh; o[6] = (OutT)sbr_clip1((xb[6] - xa[6]) / 500); o[7] = (OutT)sbr_clip1((xb[8] - xa[8]) / 8);
-    o[8] = (OutT)dsnh;
-    o[9] = (OutT)tt; o[10] = (OutT)(xr[2] / 30); o[11] = (OutT)(xr[5] / 2000); o[12] = (OutT)(xr[9] / 10);
-    o[13] = (OutT)(xr[10] / 10);
-    o[14] = (OutT)sbr_clip1((xb[2] - xa[2]) / 50); o[15] = (OutT)dxh; o[16] = (OutT)sbr_clip1((xb[9] - xa[9]) / 50);
-    o[17] = (OutT)dsnh;
+    const double tt = t_obs * 2.0;
+    const double dss = sbr_clip1((xb[2] - xa6[0]) * (1.0 / 50)), dxh = sbr_clip1((xb[5] - xa6[1]) * (1.0 / 4000));
+    const double dxa = sbr_clip1((xb[6] - xa6[2]) * (1.0 / 500)), dso = sbr_clip1((xb[8] - xa6[3]) * (1.0 / 8));
+    const double dno = sbr_clip1((xb[9] - xa6[4]) * (1.0 / 50)), dnh = sbr_clip1((xb[10] - xa6[5]) * (1.0 / 50));
+    o[0 * st] = (OutT)tt; o[1 * st] = (OutT)(xr[5] * (1.0 / 2000)); o[2 * st] = (OutT)(xr[6] * (1.0 / 500));
+    o[3 * st] = (OutT)(xr[8] * (1.0 / 8)); o[4 * st] = (OutT)(xr[10] * (1.0 / 10));
+    o[5 * st] = (OutT)dxh; o[6 * st] = (OutT)dxa; o[7 * st] = (OutT)dso; o[8 * st] = (OutT)dnh;
+    o[9 * st] = (OutT)tt; o[10 * st] = (OutT)(xr[2] * (1.0 / 30)); o[11 * st] = (OutT)(xr[5] * (1.0 / 2000));
+    o[12 * st] = (OutT)(xr[9] * (1.0 / 10)); o[13 * st] = (OutT)(xr[10] * (1.0 / 10));
+    o[14 * st] = (OutT)dss; o[15 * st] = (OutT)dxh; o[16 * st] = (OutT)dno; o[17 * st] = (OutT)dnh;
 }
 
-// state = [t, x] / x_1_state  (:153, :1020-1025)
 template <typename OutT>
-SBR_DEV void sbr_write_state(OutT* __restrict__ s, double t_obs, const double (&x)[SBR_NX]) {
-    s[0] = (OutT)(t_obs / 0.5); s[1] = (OutT)(x[0] / 1.32); s[2] = (OutT)(x[1] / 30); s[3] = (OutT)(x[2] / 30);
-    s[4] = (OutT)(x[3] / 1500); s[5] = (OutT)(x[4] / 150); s[6] = (OutT)(x[5] / 3000); s[7] = (OutT)(x[6] / 2000);
-    s[8] = (OutT)(x[7] / 600); s[9] = (OutT)(x[8] / 8); s[10] = (OutT)(x[9] / 20); s[11] = (OutT)(x[10] / 20);
-    s[12] = (OutT)(x[11] / 10); s[13] = (OutT)(x[12] / 10); s[14] = (OutT)(x[13] / 10);
+SBR_DEV void sbr_write_state(OutT* s, int st, double t_obs, const double (&x)[SBR_NX]) {
+    s[0 * st] = (OutT)(t_obs * 2.0); s[1 * st] = (OutT)(x[0] * (1.0 / 1.32)); s[2 * st] = (OutT)(x[1] * (1.0 / 30));
+    s[3 * st] = (OutT)(x[2] * (1.0 / 30)); s[4 * st] = (OutT)(x[3] * (1.0 / 1500)); s[5 * st] = (OutT)(x[4] * (1.0 / 150));
+    s[6 * st] = (OutT)(x[5] * (1.0 / 3000)); s[7 * st] = (OutT)(x[6] * (1.0 / 2000)); s[8 * st] = (OutT)(x[7] * (1.0 / 600));
+    s[9 * st] = (OutT)(x[8] * (1.0 / 8)); s[10 * st] = (OutT)(x[9] * (1.0 / 20)); s[11 * st] = (OutT)(x[10] * (1.0 / 20));
+    s[12 * st] = (OutT)(x[11] * (1.0 / 10)); s[13 * st] = (OutT)(x[12] * (1.0 / 10)); s[14 * st] = (OutT)(x[13] * (1.0 / 10));
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Terminal phases of the last call of an episode: settle (:2171-2262; v == vmax always, so the layer
 // system is linear and has the closed form below), draw + wastage (:2327-2393), idle (:2554-2597).
-SBR_DEV void sbr_terminal(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX]) {
+SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX]) {
     const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
     const double vs = x[0], z = vs / p.settler_area;
     const double t_set = p.t_settle * p.t_cycle;
@@ -293,51 +381,37 @@ SBR_DEV void sbr_terminal(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX]) {
     x[0] = resid_v;
 #pragma unroll
     for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
-    c.qw = qw;
     // idle: one DO-PID update (So[-1] == So[-2] == x[8] after settle/draw => dcv = 0), then conversion only
     const double e = c.u_do - x[8];
     c.ie_do = c.ie_do + e * p.dt;
-    double kla = p.Kc_DO * e + p.KcI_DO * c.ie_do + c.kh[SBR_KLA_HIST - 1];
+    double kla = p.Kc_DO * e + p.KcI_DO * c.ie_do + c.kla_last;
     if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - e * p.dt; }
     if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - e * p.dt; }
     const double span = p.t_cycle - t_after_draw;
     int n = (int)(span / p.dt);                       // 464 for the reference's schedule
     n = n < 0 ? 0 : (n > 100000 ? 100000 : n);        // every wave terminates whatever t holds
-    const double (&nold)[SBR_NX] = x;
-    double xi[SBR_NX];
+    double nold[SBR_NX];
 #pragma unroll
-    for (int i = 0; i < SBR_NX; ++i) xi[i] = x[i];
-    sbr_rk4<2>(p, xi, span, n, kla, 0.0, nold);
-#pragma unroll
-    for (int i = 0; i < SBR_NX; ++i) x[i] = xi[i];
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) c.kh[j] = c.kh[j + 1];
-    c.kh[SBR_KLA_HIST - 1] = kla;
+    for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
+    sbr_rk4<2>(p, x, span, n, kla, 0.0, nold);
+    sbr_hist_push(hist, kla);                         // Kla.append in Sim_idle (:2578)
+    c.kla_last = kla;
+    return qw;
 }
 
-// SbrOS.step :843-1273 for one env held in registers.  Returns the reward; xa = start of the xdot
-// span, t_obs = time the observation reports, dn = done flag.
-SBR_DEV double sbr_step_env(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1,
-                            double (&xa)[SBR_NX], double& t_obs, bool& dn) {
-    a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
-    a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
-    // four sequential tests on the running time (:860, :896, :931, :963): a call that crosses a phase
-    // boundary runs a second interval.  Envs reset together are in lockstep, so these branches are
-    // wave-uniform in practice; divergent waves are still correct.
-    if (c.t < p.T3_0) { c.u_ec = a1; c.u_do = 0.0; sbr_interval(p, c, x, xa, false); }
-    if (c.t >= p.T3_0 && c.t <= p.T3_end) { c.u_do = a0; c.u_ec = 0.0; sbr_interval(p, c, x, xa, true); }
-    if (c.t > p.T3_end && c.t <= p.T4_end) { c.u_ec = a1; c.u_do = 0.0; sbr_interval(p, c, x, xa, false); }
-    if (c.t > p.T4_end) { c.u_do = a0; c.u_ec = 0.0; sbr_interval(p, c, x, xa, true); }
-    const double r = sbr_reward(p, c, x);
-    c.ret += r; c.steps += 1.0;
+// What is left of SbrOS.step (:1011-1273) after the intervals: reward, done test, terminal phases.  Returns the reward;
+// xa6 is updated to the pre-settle values when the terminal phases run; qw is written only then.
+SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX],
+                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw) {
+    sbr_hist_apply(c, hist);
+    const double r = sbr_reward(p, c, hist, x);
     t_obs = c.t;
     dn = false;
     if (c.t >= p.T5_end) {                                               // :1122
-        dn = true; c.done = 1.0;
+        dn = true;
         if (p.terminal) {
-#pragma unroll
-            for (int i = 0; i < SBR_NX; ++i) xa[i] = x[i];
-            sbr_terminal(p, c, x);
+            sbr_take6(x, xa6);
+            qw = sbr_terminal(p, c, hist, x);
             t_obs = p.t_cycle;
         }
     }

@@ -1,0 +1,82 @@
+"""Multi-GPU: environments are independent, so the N global envs are split into contiguous blocks, one
+process (and one SbrOSVec handle) per GPU, with NO collective on the data path.  The only exchange is one
+all-gather of the per-env episode returns per episode (RCCL over xGMI on the GPU box: backend "nccl";
+"gloo" in the CPU tests).  Random streams and scenario assignment are keyed by the GLOBAL env id
+(first_env_id in the C ABI), so results do not depend on the world size.
+
+The reference has nothing distributed; this is the MI355X-side design for
+BASELINE.json configs[3].
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global, rank, world):
+    """[start, stop) of the contiguous block of global env ids owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world) or n_global < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(int(n_global), int(world))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_returns(local, n_global, group=None):
+    """All-gather the per-env episode returns of every rank into one [n_global] tensor (same on every rank),
+    ordered by global env id.  One collective: all_gather_into_tensor when the shards are equal, else a padded one."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if local.numel() != n_global:
+            raise ValueError("no process group: local shard must be the whole batch")
+        return local.clone()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    start, stop = shard_range(n_global, rank, world)
+    if local.numel() != stop - start:
+        raise ValueError("rank %d holds %d envs, expected %d" % (rank, local.numel(), stop - start))
+    local = local.contiguous()
+    if n_global % world == 0:
+        out = torch.empty(n_global, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    width = -(-n_global // world)
+    padded = torch.zeros(width, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    out = torch.empty(width * world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_range(n_global, r, world)
+        parts.append(out[r * width: r * width + (b - a)])
+    return torch.cat(parts)
+
+
+class ShardedSbrOS:
+    """This rank's block of a global batch of SBROS-v1 envs (one process per GPU)."""
+
+    def __init__(self, n_global, rank=None, world=None, device=None, **kw):
+        from .vec_env import SbrOSVec
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n_global, self.rank, self.world = int(n_global), rank, world
+        self.start, self.stop = shard_range(n_global, rank, world)
+        self.env = SbrOSVec(self.stop - self.start, device=0 if device is None else device, first_env_id=self.start, **kw)
+
+    @property
+    def global_ids(self):
+        return torch.arange(self.start, self.stop)
+
+    def reset(self, seed=0, scenario_of=lambda gid: gid % 8, **kw):
+        return self.env.reset(seed=seed, scenario=scenario_of(self.global_ids).to(torch.int32), **kw)
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def rollout(self, n_steps, policy_seed=0):
+        return self.env.rollout(n_steps, policy_seed)
+
+    def gather_episode_returns(self, dtype=torch.float32):
+        """[n_global] episode returns on every rank: the single collective of the path."""
+        return gather_returns(self.env.episode_returns().to(dtype), self.n_global)
+
+    def close(self):
+        self.env.close()

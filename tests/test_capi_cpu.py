@@ -1,0 +1,96 @@
+"""CPU-side checks of the C ABI: libsbr_amd.so loads without a GPU, exports every function include/sbr_amd.h
+declares, its defaults are the reference's constants, and - without a device - it refuses loudly instead of
+falling back to anything.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+from conftest import ROOT, golden
+
+from gym_sbr2_amd import _capi
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "sbr_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sbr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _capi.load()
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    assert declared == sorted(_capi.SYMBOLS), set(declared) ^ set(_capi.SYMBOLS)
+    raw = C.CDLL(_capi.library_path())
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert b"gfx950" in lib.sbr_version()
+
+
+def test_header_constants_match_the_binding():
+    text = open(os.path.join(ROOT, "include", "sbr_amd.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define\s+(SBR_[A-Z_]+)\s+(\d+)\s", text)}
+    assert (defs["SBR_NX"], defs["SBR_NOBS"], defs["SBR_NSTATE"], defs["SBR_NCTRL"], defs["SBR_KLA_HIST"]) == (
+        _capi.NX, _capi.NOBS, _capi.NSTATE, _capi.NCTRL, _capi.KLA_HIST)
+    assert (defs["SBR_ST_NEGATIVE"], defs["SBR_ST_NEAR_POLE"], defs["SBR_ST_NONFINITE"]) == (1, 2, 4)
+    assert _capi.C_STATUS == _capi.NCTRL - 1 and _capi.C_KLA_LAST == _capi.C_KLA_HIST0 + 9
+
+
+def test_default_config_is_the_reference():
+    c = golden("constants")
+    cfg = _capi.default_config()
+    for key, val in [("T1_end", cfg.T_fill), ("T3_0", cfg.T3_0), ("T3_end", cfg.T3_end), ("T4_end", cfg.T4_end),
+                     ("T5_end", cfg.T5_end), ("So_sat", cfg.So_sat), ("dt", cfg.dt), ("t_delta", cfg.t_delta),
+                     ("t_cycle", cfg.t_cycle), ("EC_conc", cfg.EC_conc)]:
+        assert float(c[key]) == val, key
+    assert (cfg.Kla_min, cfg.Kla_max) == tuple(c["DO_control_par"][4:6])
+    assert (cfg.EC_min, cfg.EC_max) == tuple(c["EC_control_par"][4:6])
+    assert (cfg.t_settle, cfg.t_draw) == (float(c["t_ratio"][5]), float(c["t_ratio"][6]))
+    k = golden("rhs_kat")
+    assert [cfg.Ya, cfg.Yh, cfg.fp, cfg.ixb, cfg.ixp] == k["Spar"].tolist()
+    assert [cfg.muH, cfg.Ks, cfg.Koh, cfg.Kno, cfg.bH, cfg.eta_g, cfg.eta_h, cfg.kh, cfg.Kx, cfg.muA, cfg.Knh, cfg.bA,
+            cfg.Koa, cfg.ka] == k["Kpar"].tolist()
+    assert np.array_equal(np.array(cfg.x0[:]), golden("sbros_const_2_5")["x0_init"])
+    assert (cfg.substeps, cfg.terminal, cfg.out_f64, cfg.act_f64) == (10, 1, 0, 0)
+    # the oracle's parameter block has the same layout and the same defaults
+    from oracle import sbr_oracle as O
+    p = O.default_params()
+    assert C.sizeof(p) == C.sizeof(cfg)
+    for name, _ in _capi.SbrConfig._fields_[:-5]:
+        assert getattr(p, name) == getattr(cfg, name), name
+
+
+def test_packaged_influent_tables_are_the_captured_ones():
+    from gym_sbr2_amd.vec_env import load_influent_tables
+    means, stds = load_influent_tables()
+    t = golden("influent_tables")
+    assert np.array_equal(means, t["means"]) and np.array_equal(stds, t["stds"]) and means.shape == (8, 14, 48)
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load()
+    assert lib.sbr_device_count() == 0
+    h = C.c_void_p()
+    rc = lib.sbr_create(8, 0, 0, None, C.byref(h))
+    assert rc == -2 and not h.value and b"no CPU path" in lib.sbr_last_error(None)
+    import gym_sbr2_amd
+    with pytest.raises(_capi.SbrError):
+        gym_sbr2_amd.SbrOSVec(8)
+    with pytest.raises(_capi.SbrError):
+        gym_sbr2_amd.make("SBROS-v1")
+    assert gym_sbr2_amd.registered_ids() == ["SBROS-v1"]
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under gym_sbr2_amd/ may import, load or call it."""
+    pkg = os.path.join(ROOT, "gym_sbr2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "sbr_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
