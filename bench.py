@@ -104,16 +104,29 @@ def main():
         state["episode"] += 1
         state["in_episode"] = 0
 
+    ret64 = torch.empty(n_local, dtype=torch.float64, device=dev)
+    status_snap = torch.empty(n_local, dtype=torch.float64, device=dev)
+
     def end_of_episode():
-        ret = env.episode_returns().to(torch.float32)
-        state["returns"] = gather_returns(ret, n_global) if world > 1 else ret      # configs[3]: the one collective
+        # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync):
+        # the per-env returns, collated over ranks by the one collective of the path (configs[3])
+        ret = env.episode_returns(out=ret64).to(torch.float32)
+        state["returns"] = gather_returns(ret, n_global) if world > 1 else ret
+        env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
+
+    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0}
 
     def run(k_steps, record):
         done = 0
         while done < k_steps:
             if state["in_episode"] == CALLS_PER_EPISODE:
+                ta = time.perf_counter()
                 end_of_episode()
+                tb = time.perf_counter()
                 reset()
+                if record:
+                    acct["end_of_episode_ms"] += (tb - ta) * 1e3
+                    acct["reset_issue_ms"] += (time.perf_counter() - tb) * 1e3
             m = min(k_steps - done, CALLS_PER_EPISODE - state["in_episode"])
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -135,6 +148,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # untimed priming: one pass over everything an episode boundary touches (allocator growth, lazy loading of torch's
+    # kernels, RCCL's first collective), then W warm-up steps.  Nothing here is counted.
+    reset()
+    end_of_episode()
     reset()
     run(args.warmup, record=False)
     fence()
@@ -153,7 +170,12 @@ def main():
     per_launch_s = dev_ms * 1e-3 / max(launches, 1)
     calls_per_launch = 1 if not fused else args.steps / max(len(seg_events), 1)
     achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
-    status = env.status()
+    # HBM bytes per launch from the PMC counters: collected offline with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
+    # passes, gfx950 correction calibrated in the same run) and committed under profiles/; valid for this workload only
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not fused and n_local == 65536 and os.path.exists(pmc):
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     out = {
         "metric": "env-steps/sec (batched)",
         "value": n_global * args.steps / elapsed,
@@ -168,15 +190,23 @@ def main():
                                                              "episode (configs[3] shape)" % world if world > 1 else ""),
                                 "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload],
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
-                   "resets_in_timed_region": max(state["episode"] - 1, 0), "actions": "uniform random set-points, float32, resident in HBM",
+                   "resets_in_timed_region": max(state["episode"] - 2, 0), "actions": "uniform random set-points, float32, resident in HBM",
                    "kernel": "k_rollout" if fused else "k_step<float,float,%d>" % (2 if n_local > 98304 else 1)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (profiles/r01_pmc_traffic.json: 724 B per env-step vs 513 algorithmic; every byte moves once)",
+                     "algorithmic_bytes_per_launch": n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP,
                      "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                      "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
+                     "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms,
+                                         "host_in_end_of_episode": acct["end_of_episode_ms"],
+                                         "host_in_reset_issue": acct["reset_issue_ms"]},
                      "note": "fp64 VALU-bound, not HBM-bound: ~5.7 kFLOP per env-step at ~11 FLOP/B (SURVEY.md 8d); see DESIGN.md"},
-        "env_status": {"near_pole_frac": float(((status & _capi.ST_NEAR_POLE) != 0).float().mean().item()),
-                       "nonfinite": int(((status & _capi.ST_NONFINITE) != 0).sum().item())},
+        "env_status": {"near_pole_frac_last_episode": float(((status_snap.to(torch.int64) & _capi.ST_NEAR_POLE) != 0).float().mean().item())
+                       if state["episode"] > 2 else None,
+                       "nonfinite": int(((status_snap.to(torch.int64) & _capi.ST_NONFINITE) != 0).sum().item()),
+                       "note": "uniform random set-points drive ammonia negative in most envs (the reference model has no "
+                               "guards); arithmetic cost is unaffected, see DESIGN.md"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -592,6 +592,13 @@ int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream)
     return SBR_OK;
 }
 
+int sbr_get_ctrl_row(sbr_env* e, int32_t row, double* out, void* stream) {
+    if (!e || !out || row < 0 || row >= SBR_NCTRL) return fail(e, SBR_ERR_INVALID, "sbr_get_ctrl_row: bad argument");
+    HIP_TRY(e, hipMemcpyAsync(out, e->buf.ctrl + (size_t)row * e->n, (size_t)e->n * sizeof(double),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SBR_OK;
+}
+
 int sbr_get_influent(sbr_env* e, double* out, void* stream) {
     if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_get_influent: NULL argument");
     HIP_TRY(e, hipMemcpyAsync(out, e->buf.infl, SBR_NX * (size_t)e->n * sizeof(double), hipMemcpyDeviceToDevice,

@@ -146,12 +146,18 @@ class SbrOSVec:
     def status(self):
         """Sticky domain-of-validity bits per env (int64; _capi.ST_NEGATIVE | ST_NEAR_POLE | ST_NONFINITE): the
         reference model has no guards and can be driven to negative ammonia / a Monod pole by aggressive policies."""
-        _, ctrl = self.get_state()
-        return ctrl[_capi.C_STATUS].to(torch.int64)
+        return self.ctrl_row(_capi.C_STATUS).to(torch.int64)
 
-    def episode_returns(self):
-        _, ctrl = self.get_state()
-        return ctrl[_capi.C_RETURN]
+    def ctrl_row(self, row, out=None):
+        """One row of the controller/bookkeeping block ([N] float64), copied on the current stream without a host sync."""
+        if out is None:
+            out = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.sbr_get_ctrl_row(self._h, int(row), _ptr(out), self._stream()), self._h)
+        return out
+
+    def episode_returns(self, out=None):
+        """Sum of rewards since reset, per env ([N] float64)."""
+        return self.ctrl_row(_capi.C_RETURN, out)
 
     def stats(self, values):
         v = self._dev(values, torch.float64, (values.numel(),))

@@ -152,6 +152,10 @@ int sbr_reduce_stats(sbr_env* env, const double* values, int64_t n, double* out4
 int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
 int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
 
+/* one row of the ctrl block (SBR_C_* index), e.g. SBR_C_RETURN for the episode returns: out is [N] float64, DEVICE
+ * pointer.  An asynchronous device-to-device copy of N doubles on `stream` (sbr_get_state copies all 40 rows). */
+int sbr_get_ctrl_row(sbr_env* env, int32_t row, double* out, void* stream);
+
 /* the flow-weighted influent each env was reset with (buffer_tank3.py:87-107; entry 0 = Qin/T_fill,
  * gym_SBR_oneshot.py:287): out is [SBR_NX][N] float64, DEVICE pointer. */
 int sbr_get_influent(sbr_env* env, double* out, void* stream);

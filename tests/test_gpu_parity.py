@@ -301,6 +301,37 @@ def test_config2_4096_envs_full_episode_against_oracle(G, tables):
     env.close()
 
 
+def test_two_waves_per_simd_kernel_build_matches_oracle(G, tables):
+    """Batches above 98304 envs are stepped by the second build of k_step (two waves resident per SIMD).  Lockstep
+    check of that build: 98368 envs, the oracle follows a 512-env sample (first, middle and last waves) for 60 calls,
+    crossing the anoxic -> aerobic boundary (one double step)."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n, calls = 98304 + 64, 60
+    pick = np.r_[0:192, n // 2:n // 2 + 128, n - 192:n]
+    scen = (np.arange(n) % 8).astype(np.int32)
+    env = G.SbrOSVec(n, out_dtype=torch.float64)
+    env.reset(seed=3, scenario=scen)
+    ora = O.OracleBatch(len(pick))
+    rs = np.random.RandomState(5)
+    x, ctrl = env.get_state()
+    worst = 0.0
+    for c in range(calls):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)]).astype(np.float32)
+        ora.load_state(_np(x)[:, pick], _np(ctrl)[:, pick])
+        o, s, r, d = env.step(torch.from_numpy(a).cuda())
+        oo, os_, orr, od = ora.step(a[pick].astype(np.float64))
+        x, ctrl = env.get_state()
+        g = gate(_np(x).T[pick], ora.envs["x"]).max()
+        worst = max(worst, g)
+        assert g < 1e-6 and np.array_equal(_np(d)[pick], od)
+        assert np.abs(_np(o)[pick] - oo).max() < 1e-10 and np.abs(_np(r)[pick] - orr).max() < 1e-12
+        assert np.array_equal(_np(ctrl)[_capi.C_T, pick], ora.envs["t"])
+    assert int(_np(ctrl)[_capi.C_STEPS].min()) == calls and np.isfinite(_np(x)).all()
+    print("two-wave build, lockstep worst gate %.3e" % worst)
+    env.close()
+
+
 def test_status_flags_report_leaving_the_physical_domain(G):
     """The reference silently returns garbage once a concentration is driven to a Monod pole; the library reproduces
     the numbers but raises sticky flags.  States are injected with set_state and one call is taken."""
