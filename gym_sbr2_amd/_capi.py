@@ -8,11 +8,11 @@ import os
 
 from . import build as _build
 
-NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 26, 10
+NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 23, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 # rows of the ctrl block (enum in sbr_amd.h)
-C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST, C_EC_PREV, C_U_DO, C_U_EC = range(11)
-C_KLA_HIST0 = 11
+C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
+C_KLA_HIST0 = 8
 C_KLA_LAST = C_KLA_HIST0 + KLA_HIST - 1
 C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
                                               C_KLA_LAST + 5)

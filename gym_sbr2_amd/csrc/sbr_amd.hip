@@ -19,7 +19,9 @@
 
 #include "sbr_device.h"
 
-#define SBR_BLOCK 64
+#ifndef SBR_BLOCK
+#define SBR_BLOCK 64      // one wavefront per workgroup (an experiment build uses 32: half-filled waves)
+#endif
 #define SBR_RESET_BLOCK 256     // k_reset stages 84 KiB of tables in LDS: one block per CU, so make it four waves
 static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB
 
@@ -40,35 +42,94 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i, const double (&x)[SBR_NX]) {
 #pragma unroll
     for (int j = 0; j < SBR_NX; ++j) b.x[(int64_t)j * b.n + i] = x[j];
 }
+// INTERNAL controller layout [R_NROWS][N] (the public one of sbr_amd.h is produced by k_export / consumed by k_import):
+//  * the Kla history is a RING: the value of the j-th interval since reset sits in slot (j-1) % 10, where the interval
+//    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten;
+//  * steps, status bits and the done flag share one row (meta = steps*16 + status*2 + done);
+//  * rows only read when tauD != 0 (So[-2], Sno[-2]) or only at the end of an episode (Qw) come last.
+// Per env-step the step kernel reads 18 rows and writes 11 (232 B) instead of 20 + 24 (352 B).
+enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_RING0,
+       R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_NROWS };
 #define CTRL(f) b.ctrl[(int64_t)(f) * b.n + i]
-// Rows the step consumes BEFORE the integration.  ec_prev, u_do, u_ec are always overwritten before use
-// (sbr_interval / sbr_run_intervals) and So[-2], Sno[-2] only feed the derivative term, so they are read only if tauD != 0.
+
+SBR_DEV long long ring_k(const SbrPar& p, double t) {       // intervals since reset, from the running time
+    double q = (t - p.T_fill) / p.t_delta + 0.5;
+    if (!(q >= 0.0)) q = 0.0;                                // also catches NaN
+    if (q > 1e15) q = 1e15;
+    return (long long)q;
+}
+SBR_DEV int ring_slot(long long k, int i) { return (int)((k + i) % SBR_KLA_HIST); }
+SBR_DEV double meta_pack(double steps, int status, bool done) { return steps * 16.0 + (double)(status * 2 + (done ? 1 : 0)); }
+SBR_DEV void meta_unpack(double m, double& steps, int& status, bool& done) {
+    const long long v = (long long)m;
+    done = (v & 1) != 0; status = (int)((v >> 1) & 7); steps = (double)(v >> 4);
+}
+
+// Rows the step consumes BEFORE the integration.  So[-2], Sno[-2] only feed the derivative term: read only if tauD != 0.
 SBR_DEV void load_ctl_pre(const SbrPar& p, const SbrBuf& b, int64_t i, SbrCtl& c) {
-    c.t = CTRL(SBR_C_T); c.so_m1 = CTRL(SBR_C_SO_M1); c.sno_m1 = CTRL(SBR_C_SNO_M1);
-    c.ie_do = CTRL(SBR_C_IE_DO); c.ie_ec = CTRL(SBR_C_IE_EC);
-    c.ec_last = CTRL(SBR_C_EC_LAST); c.kla_last = CTRL(SBR_C_KLA_LAST);
+    c.t = CTRL(R_T); c.so_m1 = CTRL(R_SO_M1); c.sno_m1 = CTRL(R_SNO_M1);
+    c.ie_do = CTRL(R_IE_DO); c.ie_ec = CTRL(R_IE_EC); c.ec_last = CTRL(R_EC_LAST);
     const bool deriv = (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0);            // wave-uniform
-    c.so_m2 = deriv ? CTRL(SBR_C_SO_M2) : c.so_m1;
-    c.sno_m2 = deriv ? CTRL(SBR_C_SNO_M2) : c.sno_m1;
+    c.so_m2 = deriv ? CTRL(R_SO_M2) : c.so_m1;
+    c.sno_m2 = deriv ? CTRL(R_SNO_M2) : c.sno_m1;
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
     c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
 }
-// Rows needed only AFTER the integration: the nine older Kla values (hist[9] = Kla[-1] was loaded before).
-SBR_DEV void load_hist(const SbrBuf& b, int64_t i, double kla_last_before, double (&hist)[SBR_KLA_HIST]) {
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = CTRL(SBR_C_KLA_HIST0 + j);
-    hist[SBR_KLA_HIST - 1] = kla_last_before;
+// rows every step rewrites (the ring slot(s), return and meta are written by the caller)
+SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c) {
+    CTRL(R_T) = c.t; CTRL(R_SO_M1) = c.so_m1; CTRL(R_SO_M2) = c.so_m2;
+    CTRL(R_SNO_M1) = c.sno_m1; CTRL(R_SNO_M2) = c.sno_m2;
+    CTRL(R_IE_DO) = c.ie_do; CTRL(R_IE_EC) = c.ie_ec; CTRL(R_EC_LAST) = c.ec_last;
 }
-SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], double ret,
-                       double steps, double status) {
-    CTRL(SBR_C_T) = c.t; CTRL(SBR_C_SO_M1) = c.so_m1; CTRL(SBR_C_SO_M2) = c.so_m2;
-    CTRL(SBR_C_SNO_M1) = c.sno_m1; CTRL(SBR_C_SNO_M2) = c.sno_m2;
-    CTRL(SBR_C_IE_DO) = c.ie_do; CTRL(SBR_C_IE_EC) = c.ie_ec;
-    CTRL(SBR_C_EC_LAST) = c.ec_last; CTRL(SBR_C_EC_PREV) = c.ec_prev;
-    CTRL(SBR_C_U_DO) = c.u_do; CTRL(SBR_C_U_EC) = c.u_ec;
+// whole history, logical order (oldest first), for the given interval count
+SBR_DEV void load_ring(const SbrBuf& b, int64_t i, long long k, double (&hist)[SBR_KLA_HIST]) {
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(SBR_C_KLA_HIST0 + j) = hist[j];
-    CTRL(SBR_C_RETURN) = ret; CTRL(SBR_C_STEPS) = steps; CTRL(SBR_C_STATUS) = status;
+    for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = CTRL(R_RING0 + ring_slot(k, j));
+}
+SBR_DEV void store_ring(const SbrBuf& b, int64_t i, long long k, const double (&hist)[SBR_KLA_HIST]) {
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(R_RING0 + ring_slot(k, j)) = hist[j];
+}
+
+// public <-> internal translation (sbr_get_state / sbr_set_state / sbr_get_ctrl_row); only_row < 0 = all rows
+__global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double* __restrict__ out, int only_row) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    double v[SBR_NCTRL], hist[SBR_KLA_HIST], steps;
+    int status; bool done;
+    const double t = CTRL(R_T);
+    load_ring(b, i, ring_k(p, t), hist);
+    meta_unpack(CTRL(R_META), steps, status, done);
+    v[SBR_C_T] = t; v[SBR_C_SO_M1] = CTRL(R_SO_M1); v[SBR_C_SO_M2] = CTRL(R_SO_M2);
+    v[SBR_C_SNO_M1] = CTRL(R_SNO_M1); v[SBR_C_SNO_M2] = CTRL(R_SNO_M2);
+    v[SBR_C_IE_DO] = CTRL(R_IE_DO); v[SBR_C_IE_EC] = CTRL(R_IE_EC); v[SBR_C_EC_LAST] = CTRL(R_EC_LAST);
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) v[SBR_C_KLA_HIST0 + j] = hist[j];
+    v[SBR_C_QW] = CTRL(R_QW); v[SBR_C_RETURN] = CTRL(R_RET); v[SBR_C_STEPS] = steps;
+    v[SBR_C_DONE] = done ? 1.0 : 0.0; v[SBR_C_STATUS] = (double)status;
+    if (only_row >= 0) {
+#pragma unroll
+        for (int r = 0; r < SBR_NCTRL; ++r) if (r == only_row) out[i] = v[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < SBR_NCTRL; ++r) out[(int64_t)r * b.n + i] = v[r];
+    }
+}
+__global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const double* __restrict__ in) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+#define IN(r) in[(int64_t)(r) * b.n + i]
+    const double t = IN(SBR_C_T);
+    double hist[SBR_KLA_HIST];
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = IN(SBR_C_KLA_HIST0 + j);
+    CTRL(R_T) = t; CTRL(R_SO_M1) = IN(SBR_C_SO_M1); CTRL(R_SO_M2) = IN(SBR_C_SO_M2);
+    CTRL(R_SNO_M1) = IN(SBR_C_SNO_M1); CTRL(R_SNO_M2) = IN(SBR_C_SNO_M2);
+    CTRL(R_IE_DO) = IN(SBR_C_IE_DO); CTRL(R_IE_EC) = IN(SBR_C_IE_EC); CTRL(R_EC_LAST) = IN(SBR_C_EC_LAST);
+    store_ring(b, i, ring_k(p, t), hist);
+    CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN);
+    CTRL(R_META) = meta_pack(IN(SBR_C_STEPS), (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0);
+#undef IN
 }
 
 // ------------------------------------------------------------------------------------------- reset
@@ -145,8 +206,9 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = ((SBR_KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;   // [0,k]*126, :323
     c.kla_last = kla;
     store_x(b, i, x);
-    store_ctl(b, i, c, hist, 0.0, 0.0, (double)sbr_status_bits(p, x));
-    CTRL(SBR_C_QW) = 0.0; CTRL(SBR_C_DONE) = 0.0;
+    store_ctl(b, i, c);
+    store_ring(b, i, ring_k(p, c.t), hist);          // k = 0: logical order = slot order
+    CTRL(R_RET) = 0.0; CTRL(R_META) = meta_pack(0.0, sbr_status_bits(p, x), false); CTRL(R_QW) = 0.0;
     if (obs) {   // volume blend of influent and post-fill state, :346-361
         double xr[SBR_NX];
 #pragma unroll
@@ -168,12 +230,12 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // Values that only have to SURVIVE the integration (Kla history, return/steps/status, the xdot start values: 19
 // doubles per lane) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip
 // through L2/HBM, and the RK4 loop keeps its registers.  Slot j of lane l is at park[j*64 + l] (conflict-free).
-#define SBR_NPARK (SBR_KLA_HIST - 1 + 4 + SBR_NXD)
+#define SBR_NPARK (SBR_KLA_HIST - 1 + 2 + SBR_NXD)
 template <typename OutT, typename ActT, int W>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
-                                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
-                                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
-    __shared__ double park[SBR_NPARK * SBR_BLOCK];
+                                                      OutT* __restrict__ obs, OutT* __restrict__ state,
+                                                      OutT* __restrict__ reward, uint8_t* __restrict__ done) {
+    __shared__ double park[SBR_NPARK * 64];
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= b.n) return;
     double* my = park + threadIdx.x;
@@ -181,28 +243,49 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
     SbrCtl c;
     load_x(b, i, x);
     load_ctl_pre(p, b, i, c);
-    const double kla_before = c.kla_last;
-    const double done0 = CTRL(SBR_C_DONE);
+    const long long k0 = ring_k(p, c.t);                  // intervals run before this call
+    const double meta0 = CTRL(R_META);
     const double a0 = (double)action[2 * i], a1 = (double)action[2 * i + 1];     // one 8- or 16-byte load per lane
+    c.kla_last = CTRL(R_RING0 + ring_slot(k0, SBR_KLA_HIST - 1));
+    const double kla_before = c.kla_last;
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * 64] = CTRL(SBR_C_KLA_HIST0 + j);
-    my[9 * 64] = CTRL(SBR_C_RETURN); my[10 * 64] = CTRL(SBR_C_STEPS); my[11 * 64] = CTRL(SBR_C_STATUS);
-    SbrX6Lds x6{my + 13 * 64};
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * 64] = CTRL(R_RING0 + ring_slot(k0, j));
+    my[9 * 64] = CTRL(R_RET); my[10 * 64] = meta0;
+    SbrX6Lds x6{my + 11 * 64};
     x6.put(x);
     double t_obs = p.t_cycle, r = 0.0;
     bool dn = true;
     double xa6[SBR_NXD];
-    if (done0 == 0.0) {                   // a finished env waits for sbr_reset (the reference leaves resetting to the caller)
-        double qw = 0.0, hist[SBR_KLA_HIST];
+    if (((long long)meta0 & 1) == 0) {    // not done: a finished env waits for sbr_reset (the reference leaves resetting to the caller)
+        double qw = 0.0, hist[SBR_KLA_HIST], steps;
+        int status; bool was_done;
+        const double v0 = x[0], si0 = x[1], xi0 = x[3];
         sbr_run_intervals(p, c, x, a0, a1, x6);
 #pragma unroll
         for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * 64];
         hist[SBR_KLA_HIST - 1] = kla_before;
         x6.get(xa6);
         r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
-        store_x(b, i, x);
-        store_ctl(b, i, c, hist, my[9 * 64] + r, my[10 * 64] + 1.0, (double)((int)my[11 * 64] | c.st_new));
-        if (dn) { CTRL(SBR_C_DONE) = 1.0; if (p.terminal) CTRL(SBR_C_QW) = qw; }
+        // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
+        // (wave-uniform test: no lane of the wave changed them)
+        const bool inert_moved = (x[0] != v0) || (x[1] != si0) || (x[3] != xi0);
+        if (__builtin_amdgcn_ballot_w64(inert_moved) != 0ull) {
+            store_x(b, i, x);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) b.x[(int64_t)j * b.n + i] = x[j];
+        }
+        store_ctl(b, i, c);
+        if (dn && p.terminal) {           // the idle phase appended one more Kla: the logical history moved by n_new + 1
+            store_ring(b, i, k0 + c.n_new, hist);       // rare (once per episode): rewrite the whole ring consistently with t
+            CTRL(R_QW) = qw;
+        } else {
+            CTRL(R_RING0 + ring_slot(k0, 0)) = c.knew[0];
+            if (c.n_new > 1) CTRL(R_RING0 + ring_slot(k0, 1)) = c.knew[1];
+        }
+        meta_unpack(my[10 * 64], steps, status, was_done);
+        CTRL(R_RET) = my[9 * 64] + r;
+        CTRL(R_META) = meta_pack(steps + 1.0, status | c.st_new, dn);
     } else {
         x6.get(xa6);
     }
@@ -223,28 +306,32 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
     SbrX6Reg x6;
     load_x(b, i, x);
     load_ctl_pre(p, b, i, c);
-    load_hist(b, i, c.kla_last, hist);
-    double ret = CTRL(SBR_C_RETURN), steps = CTRL(SBR_C_STEPS), done_f = CTRL(SBR_C_DONE), qw = CTRL(SBR_C_QW);
-    int status = (int)CTRL(SBR_C_STATUS);
-    c.ec_prev = CTRL(SBR_C_EC_PREV); c.u_do = CTRL(SBR_C_U_DO); c.u_ec = CTRL(SBR_C_U_EC);   // kept if nothing runs
-    c.so_m2 = CTRL(SBR_C_SO_M2); c.sno_m2 = CTRL(SBR_C_SNO_M2);
+    c.so_m2 = CTRL(R_SO_M2); c.sno_m2 = CTRL(R_SNO_M2);
+    load_ring(b, i, ring_k(p, c.t), hist);
+    c.kla_last = hist[SBR_KLA_HIST - 1];
+    double ret = CTRL(R_RET), steps, qw = CTRL(R_QW);
+    int status; bool finished;
+    meta_unpack(CTRL(R_META), steps, status, finished);
     double acc = 0.0;
     for (int32_t s = 0; s < n_steps; ++s) {
         float a0, a1;
         sbr_policy_action(p, policy_seed, gid, (uint32_t)steps, a0, a1);
         if (actions_out) reinterpret_cast<float2*>(actions_out)[(int64_t)s * b.n + i] = make_float2(a0, a1);
-        if (done_f != 0.0) continue;
+        if (finished) continue;
         double t_obs;
         bool dn;
         sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
         const double r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
         acc += r; ret += r; steps += 1.0; status |= c.st_new;
-        if (dn) done_f = 1.0;
+        if (dn) finished = true;
     }
     store_x(b, i, x);
-    store_ctl(b, i, c, hist, ret, steps, (double)status);
-    CTRL(SBR_C_DONE) = done_f; CTRL(SBR_C_QW) = qw;
+    store_ctl(b, i, c);
+    // the ring is addressed by the interval count recovered from t: store the logical history consistently with the final t
+    // (the idle phase's extra Kla does not advance t; k_export reads with the same rule)
+    store_ring(b, i, ring_k(p, c.t), hist);
+    CTRL(R_RET) = ret; CTRL(R_META) = meta_pack(steps, status, finished); CTRL(R_QW) = qw;
     if (returns) returns[i] = acc;
 }
 #undef CTRL
@@ -473,16 +560,16 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     }
     const size_t nb = (size_t)n_envs * sizeof(double);
     CREATE_TRY(hipMalloc(&e->buf.x, SBR_NX * nb));
-    CREATE_TRY(hipMalloc(&e->buf.ctrl, SBR_NCTRL * nb));
+    CREATE_TRY(hipMalloc(&e->buf.ctrl, R_NROWS * nb));
     CREATE_TRY(hipMalloc(&e->buf.infl, SBR_NX * nb));
     CREATE_TRY(hipMalloc(&e->tables, 2 * kTableDoubles * sizeof(double)));
     CREATE_TRY(hipMemset(e->buf.x, 0, SBR_NX * nb));
-    CREATE_TRY(hipMemset(e->buf.ctrl, 0, SBR_NCTRL * nb));
+    CREATE_TRY(hipMemset(e->buf.ctrl, 0, R_NROWS * nb));
     CREATE_TRY(hipMemset(e->buf.infl, 0, SBR_NX * nb));
     // an env is unusable until its first reset: mark everything done so that step() is a no-op until then
     {
-        std::vector<double> ones((size_t)n_envs, 1.0);
-        CREATE_TRY(hipMemcpy(e->buf.ctrl + (size_t)SBR_C_DONE * n_envs, ones.data(), nb, hipMemcpyHostToDevice));
+        std::vector<double> ones((size_t)n_envs, 1.0);        // meta = steps*16 + status*2 + done  =>  1.0 = "done"
+        CREATE_TRY(hipMemcpy(e->buf.ctrl + (size_t)R_META * n_envs, ones.data(), nb, hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipEventCreate(&e->ev0));
     CREATE_TRY(hipEventCreate(&e->ev1));
@@ -580,7 +667,10 @@ int sbr_get_state(sbr_env* e, double* x, double* ctrl, void* stream) {
     if (!e) return SBR_ERR_INVALID;
     const size_t nb = (size_t)e->n * sizeof(double);
     if (x) HIP_TRY(e, hipMemcpyAsync(x, e->buf.x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (ctrl) HIP_TRY(e, hipMemcpyAsync(ctrl, e->buf.ctrl, SBR_NCTRL * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ctrl) {
+        hipLaunchKernelGGL(k_export, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, ctrl, -1);
+        HIP_TRY(e, hipGetLastError());
+    }
     return SBR_OK;
 }
 
@@ -588,14 +678,22 @@ int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream)
     if (!e) return SBR_ERR_INVALID;
     const size_t nb = (size_t)e->n * sizeof(double);
     if (x) HIP_TRY(e, hipMemcpyAsync(e->buf.x, x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (ctrl) HIP_TRY(e, hipMemcpyAsync(e->buf.ctrl, ctrl, SBR_NCTRL * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ctrl) {
+        hipLaunchKernelGGL(k_import, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, ctrl);
+        HIP_TRY(e, hipGetLastError());
+    }
     return SBR_OK;
 }
 
 int sbr_get_ctrl_row(sbr_env* e, int32_t row, double* out, void* stream) {
     if (!e || !out || row < 0 || row >= SBR_NCTRL) return fail(e, SBR_ERR_INVALID, "sbr_get_ctrl_row: bad argument");
-    HIP_TRY(e, hipMemcpyAsync(out, e->buf.ctrl + (size_t)row * e->n, (size_t)e->n * sizeof(double),
-                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (row == SBR_C_RETURN) {           // stored as is: a plain device-to-device copy
+        HIP_TRY(e, hipMemcpyAsync(out, e->buf.ctrl + (size_t)R_RET * e->n, (size_t)e->n * sizeof(double),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    } else {
+        hipLaunchKernelGGL(k_export, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, out, (int)row);
+        HIP_TRY(e, hipGetLastError());
+    }
     return SBR_OK;
 }
 

@@ -38,14 +38,14 @@ extern "C" {
 #define SBR_NSAMP 48       /* samples per influent series */
 #define SBR_NSERIES 14     /* 13 concentrations + flow q */
 #define SBR_KLA_HIST 10    /* Kla values the reward can look back on (current + 9) */
-/* controller/bookkeeping doubles per env exposed by sbr_get_state/sbr_set_state, in this order */
-#define SBR_NCTRL 26
+/* controller/bookkeeping doubles per env exposed by sbr_get_state/sbr_set_state, in this order.  This is the PUBLIC
+ * layout; the kernels keep a leaner internal one (Kla history as a ring, packed bookkeeping) and translate. */
+#define SBR_NCTRL 23
 enum {
     SBR_C_T = 0,           /* running time t (days)                     gym_SBR_oneshot.py:1357 */
     SBR_C_SO_M1, SBR_C_SO_M2, SBR_C_SNO_M1, SBR_C_SNO_M2,   /* So[-1] So[-2] Sno[-1] Sno[-2]  :1959-1961 */
     SBR_C_IE_DO, SBR_C_IE_EC,                               /* PID integrals                  :1893,:1923 */
-    SBR_C_EC_LAST, SBR_C_EC_PREV,                           /* EC[-1] and EC of the interval before it */
-    SBR_C_U_DO, SBR_C_U_EC,                                 /* set-points in force            :862-906 */
+    SBR_C_EC_LAST,                                          /* EC[-1] */
     SBR_C_KLA_HIST0,                                        /* 10 entries, oldest first; the last is Kla[-1] */
     SBR_C_KLA_LAST = SBR_C_KLA_HIST0 + SBR_KLA_HIST - 1,
     SBR_C_QW,                                               /* wastage flow of the last terminal step :2376 */
@@ -54,6 +54,8 @@ enum {
     SBR_C_DONE,                                             /* 1.0 once the episode ended */
     SBR_C_STATUS                                            /* sticky SBR_ST_* bits since reset (as double) */
 };
+/* (The reference's u_DO / u_EC globals and the EC value before EC[-1] are temporaries of one step() call - every
+ * interval overwrites them before use - so they are not part of the state.) */
 
 /* Domain-of-validity flags.  The ASM1 rate expressions x/(K+x) have poles at x = -K and the reference has no
  * guards (gym_SBR_oneshot.py:1660-1685): heterotrophic growth takes up ammonia without an ammonia limitation, so an
@@ -153,7 +155,7 @@ int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
 int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
 
 /* one row of the ctrl block (SBR_C_* index), e.g. SBR_C_RETURN for the episode returns: out is [N] float64, DEVICE
- * pointer.  An asynchronous device-to-device copy of N doubles on `stream` (sbr_get_state copies all 40 rows). */
+ * pointer; asynchronous on `stream`, no host synchronisation (sbr_get_state translates all 23 rows). */
 int sbr_get_ctrl_row(sbr_env* env, int32_t row, double* out, void* stream);
 
 /* the flow-weighted influent each env was reset with (buffer_tank3.py:87-107; entry 0 = Qin/T_fill,

@@ -113,17 +113,18 @@ class OracleBatch:
         return out
 
     def load_state(self, x, ctrl):
-        """Overwrite the plant/controller state from the product's layout: x [14][n], ctrl [26][n]
-        (rows as in include/sbr_amd.h).  Used to re-synchronise the oracle to the device before a call."""
+        """Overwrite the plant/controller state from the product's PUBLIC layout: x [14][n], ctrl [23][n]
+        (rows as in include/sbr_amd.h).  Used to re-synchronise the oracle to the device before a call.  The set-points
+        in force and the EC before EC[-1] are temporaries of one call (every interval overwrites them first)."""
         x, ctrl = np.asarray(x, dtype=np.float64), np.asarray(ctrl, dtype=np.float64)
         e = self.envs
         e["x"] = x.T
-        for row, name in enumerate(["t", "so_m1", "so_m2", "sno_m1", "sno_m2", "ie_do", "ie_ec", "ec_last", "ec_prev",
-                                    "u_do", "u_ec"]):
+        for row, name in enumerate(["t", "so_m1", "so_m2", "sno_m1", "sno_m2", "ie_do", "ie_ec", "ec_last"]):
             e[name] = ctrl[row]
-        e["kla_hist"] = ctrl[11:21].T
-        e["kla_last"] = ctrl[20]
-        e["qw"], e["ret"], e["steps"], e["done"], e["status"] = ctrl[21], ctrl[22], ctrl[23], ctrl[24], ctrl[25]
+        e["ec_prev"] = ctrl[7]
+        e["kla_hist"] = ctrl[8:18].T
+        e["kla_last"] = ctrl[17]
+        e["qw"], e["ret"], e["steps"], e["done"], e["status"] = ctrl[18], ctrl[19], ctrl[20], ctrl[21], ctrl[22]
 
     def reset(self, influent):
         influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64)

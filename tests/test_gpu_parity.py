@@ -195,7 +195,6 @@ def test_open_loop_intervals_from_reference_states(G):
             ctrl[_capi.C_SNO_M1, j], ctrl[_capi.C_SNO_M2, j] = e["step_Sno_m1"][p], e["step_Sno_m2"][p]
             ctrl[_capi.C_IE_DO, j], ctrl[_capi.C_IE_EC, j] = e["step_ie_DO"][p], e["step_ie_EC"][p]
             ctrl[_capi.C_EC_LAST, j] = e["step_EC"][p]
-            ctrl[_capi.C_EC_PREV, j] = e["iv_EC"][i0 - 2] if i0 >= 2 else 0.0
             ctrl[_capi.C_KLA_HIST0:_capi.C_KLA_HIST0 + 10, j] = ([0.0] * 10 + e["iv_Kla"][:i0].tolist())[-10:]
         env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
         env.set_state(x, ctrl)
