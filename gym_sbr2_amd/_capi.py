@@ -10,6 +10,7 @@ from . import build as _build
 
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 23, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
+NTRACE = 19          # t, x[14], Kla, EC, reward, done per traced env and call
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
@@ -46,6 +47,8 @@ SYMBOLS = {
     "sbr_num_envs": (_I64, [_VP]),
     "sbr_set_influent_tables": (C.c_int, [_VP, _VP, _VP]),
     "sbr_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_reset_carry": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_set_trace": (C.c_int, [_VP, _VP, _I64, _I64]),
     "sbr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_rollout": (C.c_int, [_VP, _I32, _U64, _VP, _VP, _VP]),
     "sbr_reduce_stats": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),

@@ -27,6 +27,8 @@ static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5
 
 // ------------------------------------------------------------------------------------------- state I/O
 struct SbrBuf {
+    double* trace;  // [capacity][SBR_NTRACE][n_trace] or NULL
+    int64_t n_trace, trace_cap;
     double* x;      // [14][N]
     double* ctrl;   // [SBR_NCTRL][N]
     double* infl;   // [14][N]
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
 // ------------------------------------------------------------------------------------------- reset
 // SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
 // workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
-template <typename OutT>
+template <typename OutT, bool CARRY>
 __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
                                                     uint64_t seed, const int32_t* __restrict__ scenario,
                                                     const double* __restrict__ rnd, const double* __restrict__ influent,
@@ -181,14 +183,22 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 #pragma unroll
         for (int j = 1; j < SBR_NX; ++j) ld[j] = influent[i * SBR_NX + j];
     }
-    ld[0] = p.load0;                                                 // :287
+    // ---- start state: cfg.x0 / cfg.IV (:197-203), or with CARRY this env's own current state (x0_new / IV_new)
+    double x[SBR_NX], x0[SBR_NX];
+    double iv = p.IV, qin = p.qin;
+    if (CARRY) {
+        load_x(b, i, x0);
+        iv = x0[0]; qin = p.WV - iv;
+        ld[0] = qin / p.T_fill;
+    } else {
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) b.infl[(int64_t)j * b.n + i] = ld[j];
+        for (int j = 0; j < SBR_NX; ++j) x0[j] = p.x0[j];
+        ld[0] = p.load0;                                             // :287
+    }
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[j]; b.infl[(int64_t)j * b.n + i] = ld[j]; }
 
     // ---- fill phase, Sim_filling :1585-1654.  DO-PID at t_start == 0: ie = 0, dcv = 0, set-point 0
-    double x[SBR_NX], x0[SBR_NX];
-#pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) { x[j] = p.x0[j]; x0[j] = p.x0[j]; }
     SbrCtl c;
     double hist[SBR_KLA_HIST];
     const double e = 0.0 - x0[8];
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     if (obs) {   // volume blend of influent and post-fill state, :346-361
         double xr[SBR_NX];
 #pragma unroll
-        for (int j = 0; j < SBR_NX; ++j) xr[j] = (p.qin * ld[j] + x[j] * p.IV) / (p.qin + p.IV);
+        for (int j = 0; j < SBR_NX; ++j) xr[j] = (qin * ld[j] + x[j] * iv) / (qin + iv);
         double x06[SBR_NXD];
         sbr_take6(x0, x06);
         sbr_write_obs<OutT>(obs + i * SBR_NOBS, 1, c.t, xr, x06, x);
@@ -286,6 +296,14 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
         meta_unpack(my[10 * 64], steps, status, was_done);
         CTRL(R_RET) = my[9 * 64] + r;
         CTRL(R_META) = meta_pack(steps + 1.0, status | c.st_new, dn);
+        if (b.trace != nullptr && i < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
+            double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + i;
+            rec[0] = c.t;
+#pragma unroll
+            for (int j = 0; j < SBR_NX; ++j) rec[(int64_t)(1 + j) * b.n_trace] = x[j];
+            rec[15 * b.n_trace] = c.knew[c.n_new > 1 ? 1 : 0]; rec[16 * b.n_trace] = c.ec_last;
+            rec[17 * b.n_trace] = r; rec[18 * b.n_trace] = dn ? 1.0 : 0.0;
+        }
     } else {
         x6.get(xa6);
     }
@@ -573,10 +591,12 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     }
     CREATE_TRY(hipEventCreate(&e->ev0));
     CREATE_TRY(hipEventCreate(&e->ev1));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<float>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTableDoubles * (int)sizeof(double)));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<double>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTableDoubles * (int)sizeof(double)));
+    {
+        const int lds_bytes = 2 * kTableDoubles * (int)sizeof(double);     // 84 KiB of dynamic LDS: above the 64 KiB default
+        const void* fns[4] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
+                              reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>)};
+        for (const void* fn : fns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    }
 #undef CREATE_TRY
     e->buf.n = n_envs; e->buf.first_env_id = first_env_id;
     *out = e;
@@ -610,21 +630,38 @@ int sbr_set_influent_tables(sbr_env* e, const double* means, const double* stds)
 
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + SBR_BLOCK - 1) / SBR_BLOCK)); }
 
-int sbr_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
-              const uint8_t* mask, void* obs, void* stream) {
+static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scenario, const double* rnd,
+                      const double* influent, const uint8_t* mask, void* obs, void* stream) {
     if (!e) return SBR_ERR_INVALID;
     if (!influent && !e->have_tables)
         return fail(e, SBR_ERR_INVALID, "sbr_reset: no influent given and sbr_set_influent_tables was never called");
     HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
-    if (e->cfg.out_f64)
-        hipLaunchKernelGGL(k_reset<double>, dim3((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), dim3(SBR_RESET_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
-                           scenario, rnd, influent, mask, (double*)obs);
-    else
-        hipLaunchKernelGGL(k_reset<float>, dim3((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), dim3(SBR_RESET_BLOCK), lds, st, e->par, e->buf, e->tables, seed,
-                           scenario, rnd, influent, mask, (float*)obs);
+    const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
+#define RESET_LAUNCH(T, C) hipLaunchKernelGGL((k_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
+                                              influent, mask, (T*)obs)
+    if (e->cfg.out_f64) { if (carry) RESET_LAUNCH(double, true); else RESET_LAUNCH(double, false); }
+    else { if (carry) RESET_LAUNCH(float, true); else RESET_LAUNCH(float, false); }
+#undef RESET_LAUNCH
     HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+              const uint8_t* mask, void* obs, void* stream) {
+    return reset_impl(e, false, seed, scenario, rnd, influent, mask, obs, stream);
+}
+
+int sbr_reset_carry(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+                    const uint8_t* mask, void* obs, void* stream) {
+    return reset_impl(e, true, seed, scenario, rnd, influent, mask, obs, stream);
+}
+
+int sbr_set_trace(sbr_env* e, double* buf, int64_t n_envs, int64_t capacity) {
+    if (!e || (buf && (n_envs <= 0 || n_envs > e->n || capacity <= 0)))
+        return fail(e, SBR_ERR_INVALID, "sbr_set_trace: need 0 < n_envs <= N and capacity > 0");
+    e->buf.trace = buf; e->buf.n_trace = buf ? n_envs : 0; e->buf.trace_cap = buf ? capacity : 0;
     return SBR_OK;
 }
 

@@ -51,13 +51,15 @@ class SbrOS:
         o = obs_row.tolist()
         return o[:9], o[9:]
 
-    def reset(self, rnd=None, scenario=None, influent=None):
+    def reset(self, rnd=None, scenario=None, influent=None, carry_over=False):
         """rnd: the 48 standard normals buffer_tank3.py:68 would draw (None: drawn on the device from
-        `seed` + episode count); scenario: 0..7 (None = 6, as the reference :180)."""
+        `seed` + episode count); scenario: 0..7 (None = 6, as the reference :180); carry_over: start the new cycle
+        from the state the last one ended in (the reference's disabled x0_new / IV_new, :260-268)."""
         seed = (0 if self._seed is None else int(self._seed)) + self._episodes
         self._episodes += 1
         self._rewards, self._states = [], []
-        obs = self._vec.reset(seed=seed,
+        self._trace = self._vec.enable_trace(1, 464)
+        obs = self._vec.reset(seed=seed, carry_over=carry_over,
                               scenario=None if scenario is None else [int(scenario)],
                               rnd=None if rnd is None else np.asarray(rnd, dtype=np.float64)[None],
                               influent=None if influent is None else np.asarray(influent, dtype=np.float64)[None])
@@ -86,7 +88,14 @@ class SbrOS:
         return out
 
     def trajectory(self):
-        return {"reward_t": list(self._rewards), "state_t": [s.copy() for s in self._states]}
+        """Per-call records of the running episode (the reference returns 18 growing lists sampled on LSODA's output
+        grid, :1275-1288; this build records the end of every call on the device): t_t, x_t [calls,14], Kla, EC,
+        reward_t, plus the normalised states returned by step()."""
+        n = len(self._rewards)
+        rec = self._trace[:n, :, 0].cpu().numpy()
+        return {"t_t": rec[:, 0], "x_t": rec[:, 1:15], "Kla": rec[:, 15], "EC": rec[:, 16], "reward_t": rec[:, 17],
+                "So_t": rec[:, 9], "Ss_t": rec[:, 3], "Sno_t": rec[:, 10], "Snh_t": rec[:, 11],
+                "state_t": [s.copy() for s in self._states]}
 
     def render(self, mode="human"):
         return None

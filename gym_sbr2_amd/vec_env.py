@@ -93,15 +93,18 @@ class SbrOSVec:
             pass
 
     # ------------------------------------------------------------------ the gym-like surface
-    def reset(self, seed=0, scenario=None, rnd=None, influent=None, mask=None):
+    def reset(self, seed=0, scenario=None, rnd=None, influent=None, mask=None, carry_over=False):
+        """carry_over=True starts the new cycle from each env's own current state (multi-cycle operation: x0 := x,
+        IV := x[0]; disabled in the reference, gym_SBR_oneshot.py:260-268) instead of the configured start state."""
         n = self.num_envs
         sc = self._dev(scenario, torch.int32, (n,))
         rn = self._dev(rnd, torch.float64, (n, _capi.NSAMP))
         inf = self._dev(influent, torch.float64, (n, _capi.NX))
         mk = self._dev(mask, torch.uint8, (n,))
         with torch.cuda.device(self.device):
-            _capi.check(self.lib.sbr_reset(self._h, C.c_uint64(int(seed)), _ptr(sc), _ptr(rn), _ptr(inf), _ptr(mk),
-                                           _ptr(self.obs), self._stream()), self._h)
+            fn = self.lib.sbr_reset_carry if carry_over else self.lib.sbr_reset
+            _capi.check(fn(self._h, C.c_uint64(int(seed)), _ptr(sc), _ptr(rn), _ptr(inf), _ptr(mk), _ptr(self.obs),
+                           self._stream()), self._h)
         self._keep = (sc, rn, inf, mk)      # keep inputs alive until the stream has consumed them
         return self.obs
 
@@ -124,6 +127,18 @@ class SbrOSVec:
         _capi.check(self.lib.sbr_rollout(self._h, int(n_steps), C.c_uint64(int(policy_seed)), _ptr(ret), _ptr(acts),
                                          self._stream()), self._h)
         return (ret, acts) if return_actions else ret
+
+    def enable_trace(self, n_envs=1, capacity=463):
+        """Trajectory export: every step() appends [t, x(14), Kla, EC, reward, done] for the first n_envs envs at index =
+        calls since reset.  Returns the buffer [capacity, 19, n_envs] float64 (NaN where nothing was written)."""
+        self._trace = torch.full((int(capacity), _capi.NTRACE, int(n_envs)), float("nan"), dtype=torch.float64,
+                                 device=self.device)
+        _capi.check(self.lib.sbr_set_trace(self._h, _ptr(self._trace), int(n_envs), int(capacity)), self._h)
+        return self._trace
+
+    def disable_trace(self):
+        _capi.check(self.lib.sbr_set_trace(self._h, None, 0, 0), self._h)
+        self._trace = None
 
     # ------------------------------------------------------------------ inspection / parity injection
     def get_state(self):

@@ -132,6 +132,22 @@ int sbr_set_influent_tables(sbr_env* env, const double* means_host, const double
 int sbr_reset(sbr_env* env, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
               const uint8_t* mask, void* obs, void* stream);
 
+/* multi-cycle operation: like sbr_reset, but every selected env starts the new cycle from ITS OWN current
+ * state - x0 := x (normally the state after the idle phase), inoculum volume IV := x[0], inflow := (WV - IV)/T_fill -
+ * instead of cfg.x0 / cfg.IV.  This is what the reference prepares (x0_new, IV_new at gym_SBR_env2.py:152-153) and then
+ * leaves disabled (gym_SBR_oneshot.py:260-268: "IV = IV_init  # IV_new"), so there is no reference output to compare
+ * with: parity is pinned device-vs-oracle only. */
+int sbr_reset_carry(sbr_env* env, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+                    const uint8_t* mask, void* obs, void* stream);
+
+/* trajectory export (replaces the growing lists of SbrOS.trajectory(), gym_SBR_oneshot.py:1275-1288): while a trace
+ * buffer is set, every sbr_step call appends one record for each of the first n_envs environments at index = calls since
+ * reset (records beyond capacity are dropped).  buf is [capacity][SBR_NTRACE][n_envs] float64, DEVICE pointer, owned by
+ * the caller; buf = NULL switches tracing off.  Record: t, x[14] (end of the call), Kla, EC (of the last interval),
+ * reward, done. */
+#define SBR_NTRACE 19
+int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity);
+
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
  * one (at phase boundaries two) control interval(s) of RK4, reward, observations, and on the last
  * call of an episode the settle/draw/idle phases.  Any of obs/state/reward/done may be NULL. */

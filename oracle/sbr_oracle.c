@@ -256,14 +256,28 @@ static void build_state(double t_obs, const double* x, double* state) {
 /* ---------------------------------------------------------------------------------- reset */
 /* SbrOS.reset :168-438 with Sim_filling :1585-1654.  influent_in[14]: flow-weighted influent
  * ([0] is overwritten by Qin/T_fill as at :287).  obs may be NULL. */
+static void reset_from(const sbro_params* p, sbro_env* e, const double* influent_in, const double* x0, double iv, double* obs);
+
 void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, double* obs) {
-    const double qin = p->WV - p->IV;
+    reset_from(p, e, influent_in, p->x0, p->IV, obs);
+}
+
+/* multi-cycle operation: the new cycle starts from the env's own current state, x0 := x, IV := x[0]
+ * (x0_new / IV_new, gym_SBR_env2.py:152-153; disabled upstream at gym_SBR_oneshot.py:260-268) */
+void sbro_reset_carry(const sbro_params* p, sbro_env* e, const double* influent_in, double* obs) {
+    double x0[NX];
+    memcpy(x0, e->x, sizeof x0);
+    reset_from(p, e, influent_in, x0, x0[0], obs);
+}
+
+static void reset_from(const sbro_params* p, sbro_env* e, const double* influent_in, const double* x0v, double iv, double* obs) {
+    const double qin = p->WV - iv;
     memcpy(e->influent, influent_in, sizeof e->influent);
     e->influent[0] = qin / p->T_fill;
-    memcpy(e->x, p->x0, sizeof e->x);
+    memcpy(e->x, x0v, sizeof e->x);
     e->u_do = 0; e->u_ec = 15;
     /* DO-PID at t_start == 0: ie = 0, dcv = 0, set-point 0 (:1593-1617) */
-    const double err = 0 - p->x0[8];
+    const double err = 0 - x0v[8];
     double ie = 0;
     double kla = p->Kc_DO * err + p->Kc_DO / p->tauI_DO * ie + p->Kc_DO * p->tauD_DO * 0 + 0;
     if (kla > p->Kla_max) { kla = p->Kla_max; ie = ie - err * p->dt; }
@@ -274,8 +288,8 @@ void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, do
     double x0c[NX];
     memcpy(x0c, e->x, sizeof x0c);
     rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);
-    e->so_m2 = p->x0[8]; e->so_m1 = e->x[8];
-    e->sno_m2 = p->x0[9]; e->sno_m1 = e->x[2];          /* :1652 stores Ss in the Sno memory */
+    e->so_m2 = x0v[8]; e->so_m1 = e->x[8];
+    e->sno_m2 = x0v[9]; e->sno_m1 = e->x[2];          /* :1652 stores Ss in the Sno memory */
     e->t = t_end;
     /* Kla list = [0, kla] replicated (:323): the tail alternates, newest = kla */
     for (int j = 0; j < KLA_HIST; ++j) e->kla_hist[j] = ((KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;
@@ -287,7 +301,7 @@ void sbro_reset(const sbro_params* p, sbro_env* e, const double* influent_in, do
     if (obs) {
         /* volume blend of influent and post-fill state (:346-361) */
         double xr[NX];
-        for (int i = 0; i < NX; ++i) xr[i] = (qin * e->influent[i] + e->x[i] * p->IV) / (qin + p->IV);
+        for (int i = 0; i < NX; ++i) xr[i] = (qin * e->influent[i] + e->x[i] * iv) / (qin + iv);
         build_obs(e->t, xr, x0c, e->x, obs);
     }
 }
@@ -454,6 +468,11 @@ void sbro_batch_reset(const sbro_params* p, int64_t n, sbro_env* envs, const dou
                       double* obs /* [n][18] or NULL */, int nthreads) {
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int64_t i = 0; i < n; ++i) sbro_reset(p, envs + i, influent + i * NX, obs ? obs + i * 18 : 0);
+}
+
+void sbro_batch_reset_carry(const sbro_params* p, int64_t n, sbro_env* envs, const double* influent, double* obs, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) sbro_reset_carry(p, envs + i, influent + i * NX, obs ? obs + i * 18 : 0);
 }
 
 void sbro_batch_step(const sbro_params* p, int64_t n, sbro_env* envs, const double* action, double* obs, double* state,

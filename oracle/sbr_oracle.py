@@ -133,6 +133,14 @@ class OracleBatch:
                                C.c_int(self.nthreads))
         return obs
 
+    def reset_carry(self, influent):
+        """New cycle from each env's own current state (x0 := x, IV := x[0])."""
+        influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64)
+        obs = np.empty((self.n, NOBS))
+        lib().sbro_batch_reset_carry(C.byref(self.p), C.c_int64(self.n), self._envp(), _p(influent), _p(obs),
+                                     C.c_int(self.nthreads))
+        return obs
+
     def step(self, action, want_obs=True):
         # float64 actions, like the reference; to mirror the product (float32 action tensors) pass
         # actions.astype(np.float32) - the values are then used exactly

@@ -442,6 +442,69 @@ def test_size_independent_properties_at_65536(G):
     env.close(); small.close()
 
 
+def test_trajectory_export_matches_reference_per_call(G, tables):
+    """sbr_set_trace: one record per call for the traced envs.  Compared with what the reference logged per call in the
+    six golden episodes (float64 actions), and with the oracle for the traced subset of a bigger batch."""
+    from gym_sbr2_amd import _capi
+    E, env, ora, acts, _, _, ncall = _run_golden_batch(G, tables, torch.float64)
+    tr = env.enable_trace(n_envs=4, capacity=ncall + 5)      # first four episodes only
+    env.reset(rnd=np.stack([e["rnd"] for e in E]))            # tracing starts with the next reset
+    for c in range(ncall):
+        env.step(torch.from_numpy(acts[c]).cuda())
+    tr = _np(tr)
+    assert np.isnan(tr[ncall:]).all() and np.isfinite(tr[:ncall]).all()
+    for i in range(4):
+        e = E[i]
+        assert np.array_equal(tr[:ncall, 0, i], e["step_t"])                              # time recurrence is exact
+        assert np.array_equal(tr[:ncall, 18, i], e["step_done"].astype(float))
+        if EPISODES[i] in CLOSED_LOOP_OK:
+            assert gate(tr[:ncall - 1, 1:15, i], e["step_x_end"][:ncall - 1]).max() <= 1.0
+            assert np.abs(tr[:ncall, 17, i] - e["step_reward"]).max() < 5e-7
+            assert np.abs(tr[:ncall - 1, 15, i] - e["step_Kla"][:ncall - 1]).max() < 3e-3      # RK4 vs reference, closed loop: measured <= 3.0e-4 (range 0..240)
+    x, ctrl = env.get_state()
+    assert np.array_equal(tr[ncall - 1, 1:15, :], _np(x)[:, :4])                          # last record = final state
+    env.disable_trace()
+    env.close()
+
+
+def test_multi_cycle_carry_over_against_oracle(G, tables):
+    """sbr_reset_carry: the next cycle starts from the state the last one ended in (x0 := x after idle, IV := V).  The
+    reference prepares this (x0_new, IV_new) but keeps it disabled, so this is pinned device-vs-oracle only: three
+    consecutive cycles of 64 envs with held set-points that keep the plant physical."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 64
+    scen = (np.arange(n) % 8).astype(np.int32)
+    rs = np.random.RandomState(11)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    ora = O.OracleBatch(n)
+    a = np.column_stack([rs.uniform(0.5, 2.5, n), rs.uniform(2, 12, n)])
+    vols = []
+    for cycle in range(3):
+        z = rs.randn(n, 48)
+        infl = ora.mix(means, stds, scen, z)
+        if cycle == 0:
+            obs = _np(env.reset(scenario=scen, rnd=z)); oobs = ora.reset(infl)
+        else:
+            obs = _np(env.reset(scenario=scen, rnd=z, carry_over=True)); oobs = ora.reset_carry(infl)
+        x, ctrl = env.get_state()
+        assert np.abs(obs - oobs).max() < 1e-10 and gate(_np(x).T, ora.envs["x"]).max() < 1e-6
+        assert np.abs(_np(env.influent()).T - ora.envs["influent"]).max() < 1e-9          # inflow = (WV - IV)/T_fill per env
+        assert np.all(_np(ctrl)[_capi.C_DONE] == 0) and np.all(_np(ctrl)[_capi.C_STEPS] == 0)
+        for c in range(463):
+            o, s, r, d = env.step(torch.from_numpy(a).cuda())
+            oo, os_, orr, od = ora.step(a)
+        x, ctrl = env.get_state()
+        assert np.all(_np(d) == 1) and np.array_equal(_np(d), od)
+        clean = ((_np(ctrl)[_capi.C_STATUS].astype(int) | ora.envs["status"].astype(int)) & _capi.ST_NEAR_POLE) == 0
+        assert clean.sum() >= n // 2
+        assert gate(_np(x).T[clean], ora.envs["x"][clean]).max() < 1e-6
+        assert np.abs(_np(ctrl)[_capi.C_RETURN] - ora.envs["ret"])[clean].max() < 1e-10
+        vols.append(_np(x)[0].copy())
+    assert np.all(vols[0] < 1.32) and not np.allclose(vols[0], vols[1])                     # cycles differ: state is carried
+    env.close()
+
+
 def test_reference_shaped_single_env(G):
     """The N = 1 class keeps the reference's surface: reset() -> (list9, list9); step -> 5-tuple (:438, :1273)."""
     e = golden("sbros_const_2_5")
@@ -457,7 +520,12 @@ def test_reference_shaped_single_env(G):
             assert abs(reward - e["step_reward"][k]) < 1e-5 * abs(e["step_reward"][k])
         total += reward; k += 1
     assert k == 463 and abs(total / float(e["episode_return"]) - 1) < 1e-5      # reference: -0.87896708834557
+    tr = env.trajectory()
+    assert tr["x_t"].shape == (463, 14) and np.array_equal(tr["t_t"], e["step_t"])
+    assert np.abs(tr["reward_t"] - e["step_reward"]).max() < 5e-7 and abs(tr["reward_t"].sum() - total) < 1e-12
     assert [a.tolist() for a in env.get_available_actions([0.05, 12.0], 2, 3)] == [[0.0, 1.0, 1.0], [1.0, 1.0, 0.0]]
+    obs2 = env.reset(rnd=e["rnd"], carry_over=True)          # second cycle from where the first one ended
+    assert len(obs2[0]) == 9 and obs2[0] != obs[0]
     with pytest.raises(NotImplementedError):
         G.make("SBR-v2")
     env.close()
