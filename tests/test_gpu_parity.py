@@ -331,6 +331,38 @@ def test_two_waves_per_simd_kernel_build_matches_oracle(G, tables):
     env.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 65, 130])
+def test_ragged_batch_sizes(G, tables, n):
+    """Batches that do not fill their last wave (every other test uses multiples of 64): reset, 70 calls across the first
+    phase boundary, rollout, export/import round trip - against the oracle, and nothing written out of bounds."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    scen = (np.arange(n) % 8).astype(np.int32)
+    rs = np.random.RandomState(n)
+    z = rs.randn(n, 48)
+    env = G.SbrOSVec(n, out_dtype=torch.float32)
+    ora = O.OracleBatch(n)
+    guard = torch.full((n + 64, 18), -7.0, device="cuda")          # obs buffer with a canary tail
+    env.obs = guard[:n]
+    obs = _np(env.reset(scenario=scen, rnd=z)); oobs = ora.reset(ora.mix(means, stds, scen, z))
+    assert np.abs(obs - oobs).max() < 1e-5 and bool((guard[n:] == -7.0).all())
+    for c in range(70):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)]).astype(np.float32)
+        o, s, r, d = env.step(torch.from_numpy(a).cuda())
+        oo, os_, orr, od = ora.step(a.astype(np.float64))
+        assert np.allclose(_np(o), oo, rtol=2e-6, atol=1e-6) and np.allclose(_np(r), orr, rtol=2e-6, atol=1e-9)
+        assert np.array_equal(_np(d), od)
+    assert bool((guard[n:] == -7.0).all())
+    x, ctrl = env.get_state()
+    assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6 and np.array_equal(_np(ctrl)[_capi.C_STEPS], np.full(n, 70.0))
+    env.set_state(x, ctrl)                                           # export -> import is the identity
+    x2, ctrl2 = env.get_state()
+    assert torch.equal(x, x2) and torch.equal(ctrl, ctrl2)
+    ret = env.rollout(30, policy_seed=4)
+    assert np.abs(_np(ret) - ora.rollout(30, 4)).max() < 1e-9 and _np(ret).shape == (n,)
+    env.close()
+
+
 def test_status_flags_report_leaving_the_physical_domain(G):
     """The reference silently returns garbage once a concentration is driven to a Monod pole; the library reproduces
     the numbers but raises sticky flags.  States are injected with set_state and one call is taken."""
