@@ -17,6 +17,12 @@ def __getattr__(name):          # torch is imported only when the env classes ar
     if name == "SbrOS":
         from .envs import SbrOS
         return SbrOS
+    if name == "SbrEnv2Vec":
+        from .cycle_env import SbrEnv2Vec
+        return SbrEnv2Vec
+    if name == "SbrEnv2":
+        from .envs import SbrEnv2
+        return SbrEnv2
     if name == "ShardedSbrOS":
         from .sharding import ShardedSbrOS
         return ShardedSbrOS

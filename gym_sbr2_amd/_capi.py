@@ -10,6 +10,7 @@ from . import build as _build
 
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 23, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
+NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
 NTRACE = 19          # t, x[14], Kla, EC, reward, done per traced env and call
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
@@ -27,6 +28,8 @@ _DBL = ("Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka 
 
 class SbrConfig(C.Structure):
     _fields_ = [(n, C.c_double) for n in _DBL] + [
+        ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
+        ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
         ("terminal", C.c_int32), ("act_f64", C.c_int32)]
 
@@ -50,6 +53,8 @@ SYMBOLS = {
     "sbr_reset_carry": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_set_trace": (C.c_int, [_VP, _VP, _I64, _I64]),
     "sbr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_cycle_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
+    "sbr_cycle_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_rollout": (C.c_int, [_VP, _I32, _U64, _VP, _VP, _VP]),
     "sbr_reduce_stats": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "sbr_get_state": (C.c_int, [_VP, _VP, _VP, _VP]),

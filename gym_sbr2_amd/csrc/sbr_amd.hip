@@ -134,30 +134,13 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
 #undef IN
 }
 
-// ------------------------------------------------------------------------------------------- reset
-// SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
-// workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
-template <typename OutT, bool CARRY>
-__global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
-                                                    uint64_t seed, const int32_t* __restrict__ scenario,
-                                                    const double* __restrict__ rnd, const double* __restrict__ influent,
-                                                    const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][14][48]
-    const bool need_tables = (influent == nullptr);
+// influent_mixed for one lane (buffer_tank3.py:68-107): series = mean + std*rnd with ONE rnd vector shared by all series,
+// flow-weighted means, sums accumulated in sample order like python's sum().  ld[1..13]; ld[0] is set by the caller.
+SBR_DEV void influent_lane(const double* lds, bool need_tables, const int32_t* __restrict__ scenario, int default_scenario,
+                           const double* __restrict__ rnd, const double* __restrict__ influent, uint64_t seed, uint64_t gid,
+                           int64_t i, double (&ld)[SBR_NX]) {
     if (need_tables) {
-        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
-        __syncthreads();
-    }
-    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
-    if (i >= b.n) return;
-    if (mask != nullptr && mask[i] == 0) return;
-    const uint64_t gid = (uint64_t)(b.first_env_id + i);
-
-    // ---- influent_mixed (buffer_tank3.py:68-107): series = mean + std*rnd, flow-weighted means,
-    //      sums accumulated in sample order like python's sum()
-    double ld[SBR_NX];
-    if (need_tables) {
-        int s = scenario ? scenario[i] : 6;                          // :180
+        int s = scenario ? scenario[i] : default_scenario;
         s = s < 0 ? 0 : (s >= SBR_NSCEN ? SBR_NSCEN - 1 : s);        // never index LDS out of range
         const double* mu = lds + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
         const double* sd = lds + kTableDoubles + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
@@ -183,6 +166,31 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 #pragma unroll
         for (int j = 1; j < SBR_NX; ++j) ld[j] = influent[i * SBR_NX + j];
     }
+    ld[0] = 0.66;                                                    // buffer_tank3.py:107; callers overwrite it
+}
+
+// ------------------------------------------------------------------------------------------- reset
+// SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
+// workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
+template <typename OutT, bool CARRY>
+__global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
+                                                    uint64_t seed, const int32_t* __restrict__ scenario,
+                                                    const double* __restrict__ rnd, const double* __restrict__ influent,
+                                                    const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][14][48]
+    const bool need_tables = (influent == nullptr);
+    if (need_tables) {
+        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    const uint64_t gid = (uint64_t)(b.first_env_id + i);
+
+    double ld[SBR_NX];
+    influent_lane(lds, need_tables, scenario, 6 /* :180 */, rnd, influent, seed, gid, i, ld);
+
     // ---- start state: cfg.x0 / cfg.IV (:197-203), or with CARRY this env's own current state (x0_new / IV_new)
     double x[SBR_NX], x0[SBR_NX];
     double iv = p.IV, qin = p.qin;
@@ -352,6 +360,63 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
     CTRL(R_RET) = ret; CTRL(R_META) = meta_pack(steps, status, finished); CTRL(R_QW) = qw;
     if (returns) returns[i] = acc;
 }
+// ------------------------------------------------------------------------------------------- per-cycle env (SBR-v2)
+// SbrEnv2.reset (gym_SBR_env2.py:69-129): influent draw (scenario 0 by default, :104) and the 3-element observation built
+// from the sums of start state and influent.  CARRY keeps each env's current state as the start state (x0_new, :152).
+template <typename OutT, bool CARRY>
+__global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
+                                                                uint64_t seed, const int32_t* __restrict__ scenario,
+                                                                const double* __restrict__ rnd, const double* __restrict__ influent,
+                                                                const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const bool need_tables = (influent == nullptr);
+    if (need_tables) {
+        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    double ld[SBR_NX], x0[SBR_NX];
+    influent_lane(lds, need_tables, scenario, 0, rnd, influent, seed, (uint64_t)(b.first_env_id + i), i, ld);
+    if (CARRY) load_x(b, i, x0);
+    else {
+#pragma unroll
+        for (int j = 0; j < SBR_NX; ++j) x0[j] = p.x0[j];
+        store_x(b, i, x0);
+    }
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) b.infl[(int64_t)j * b.n + i] = ld[j];
+    CTRL(R_T) = 0.0; CTRL(R_RET) = 0.0; CTRL(R_QW) = 0.0;
+    CTRL(R_META) = meta_pack(0.0, sbr_status_bits(p, x0), true);     // inert for sbr_step: this handle runs whole cycles
+    if (obs) {
+        const double cod = (x0[1] + ld[1]) + (x0[2] + ld[2]) + (x0[3] + ld[3]) + (x0[4] + ld[4]) + (x0[5] + ld[5]) +
+                           (x0[6] + ld[6]) + (x0[7] + ld[7]);
+        obs[i * 3 + 0] = (OutT)(x0[0] + ld[0]); obs[i * 3 + 1] = (OutT)((cod - 5145) / 10); obs[i * 3 + 2] = (OutT)((x0[10] + ld[10]) / 30);
+    }
+}
+
+// SbrEnv2.step: one whole 12 h cycle per env (528 control intervals x 10 RK4 substeps) in one launch.
+template <typename OutT, typename ActT>
+__global__ __launch_bounds__(SBR_BLOCK) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
+                                                    OutT* __restrict__ reward, double* __restrict__ diag) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= b.n) return;
+    double x[SBR_NX], ld[SBR_NX], o3[3];
+    load_x(b, i, x);
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) ld[j] = b.infl[(int64_t)j * b.n + i];
+    ld[0] = (p.WV - x[0]) / p.t_ph[0];                                // Qin / (t_cycle * t_ratio[0]), gym_SBR_env2.py:144
+    const double st0 = (double)sbr_status_bits(p, x);
+    const double r = sbr_cycle_env(p, x, ld, (double)action[3 * i], (double)action[3 * i + 1], (double)action[3 * i + 2], o3,
+                                   diag ? diag + i * SBR_NCYC_DIAG : nullptr, 1);
+    store_x(b, i, x);
+    CTRL(R_RET) = CTRL(R_RET) + r; CTRL(R_T) = p.t_cycle;
+    CTRL(R_META) = meta_pack(1.0, (int)st0 | sbr_status_bits(p, x), true);
+    if (obs) { obs[i * 3 + 0] = (OutT)o3[0]; obs[i * 3 + 1] = (OutT)o3[1]; obs[i * 3 + 2] = (OutT)o3[2]; }
+    if (reward) reward[i] = (OutT)r;
+}
+
 #undef CTRL
 
 // ------------------------------------------------------------------------------------------- stats
@@ -481,6 +546,8 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.settler_vmax = c.settler_vmax;
     memcpy(p.x0, c.x0, sizeof p.x0);
     p.muH_etag = c.muH * c.eta_g;
+    for (int k = 0; k < 8; ++k) p.t_ph[k] = c.t_cycle * c.t_ratio[k];
+    p.cyc_Kc = c.cyc_Kc; p.cyc_KcI = c.cyc_Kc / c.cyc_tauI; p.cyc_KcD = c.cyc_Kc * c.cyc_tauD; p.cyc_dt = c.cyc_dt;
     p.substeps = c.substeps; p.terminal = c.terminal;
     p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
     p.pad_ = 0;
@@ -517,6 +584,9 @@ int sbr_default_config(sbr_config* c) {
     c->EC_min = 0; c->EC_max = 0.0005; c->Kc_EC = 100; c->tauI_EC = 20; c->tauD_EC = 0; c->EC_conc = 1200000 * 4.0;
     c->act_DO_max = 8; c->act_EC_max = 15;
     c->biomass_setpoint = 2700; c->Qeff = 0.66; c->settler_area = (1.25 / 2) * (1.25 / 2); c->settler_vmax = 474;
+    static const double tr[8] = {4.2 / 100, 8.3 / 100, 37.5 / 100, 31.2 / 100, 2.1 / 100, 8.3 / 100, 2.1 / 100, 6.3 / 100};
+    memcpy(c->t_ratio, tr, sizeof tr);
+    c->cyc_Kc = 5.0; c->cyc_tauI = 0.00035; c->cyc_tauD = 0.005; c->cyc_dt = 0.02 / 24;      // gym_SBR_env2.py:48
     static const double x0[SBR_NX] = {0.6161484733495801, 30, 0.571098000538576, 1440.01157895393, 31.254221999137,
                                       2599.2714348941, 168.915006750837, 551.901552960823, 2.16607843793004,
                                       13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
@@ -556,7 +626,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     // (the reference's schedule: phases of 46, 190, 171 and 1 intervals; the last phase is open-ended)
     if (!(c.T3_0 - c.T_fill > c.t_delta) || !(c.T3_end - c.T3_0 > c.t_delta) || !(c.T4_end - c.T3_end > c.t_delta))
         bad = "phases 2, 3 and 4 must each be longer than t_delta";
-    if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0)) bad = "tauI must be non-zero";
+    if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0) || !(c.cyc_tauI != 0) || !(c.cyc_dt > 0)) bad = "tauI must be non-zero, cyc_dt positive";
+    for (int k = 0; k < 8; ++k) if (!(c.t_ratio[k] > 0)) bad = "t_ratio entries must be positive";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }
     derive_params(c, e->par);
 #define CREATE_TRY(call)                                                                         \
@@ -596,6 +667,9 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
         const void* fns[4] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
                               reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>)};
         for (const void* fn : fns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        const void* cfns[4] = {reinterpret_cast<const void*>(&k_cycle_reset<float, false>), reinterpret_cast<const void*>(&k_cycle_reset<float, true>),
+                               reinterpret_cast<const void*>(&k_cycle_reset<double, false>), reinterpret_cast<const void*>(&k_cycle_reset<double, true>)};
+        for (const void* fn : cfns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     }
 #undef CREATE_TRY
     e->buf.n = n_envs; e->buf.first_env_id = first_env_id;
@@ -675,6 +749,36 @@ int sbr_step(sbr_env* e, const void* action, void* obs, void* state, void* rewar
         if (e->cfg.act_f64) launch_step<float, double>(e, action, obs, state, reward, done, st);
         else launch_step<float, float>(e, action, obs, state, reward, done, st);
     }
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_cycle_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+                    const uint8_t* mask, int32_t carry_over, void* obs, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    if (!influent && !e->have_tables)
+        return fail(e, SBR_ERR_INVALID, "sbr_cycle_reset: no influent given and sbr_set_influent_tables was never called");
+    HIP_TRY(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
+    const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
+#define CRESET(T, C) hipLaunchKernelGGL((k_cycle_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
+                                        influent, mask, (T*)obs)
+    if (e->cfg.out_f64) { if (carry_over) CRESET(double, true); else CRESET(double, false); }
+    else { if (carry_over) CRESET(float, true); else CRESET(float, false); }
+#undef CRESET
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, double* diag, void* stream) {
+    if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_cycle_step: NULL env or action");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
+#define CSTEP(T, A) hipLaunchKernelGGL((k_cycle<T, A>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
+    if (e->cfg.out_f64) { if (e->cfg.act_f64) CSTEP(double, double); else CSTEP(double, float); }
+    else { if (e->cfg.act_f64) CSTEP(float, double); else CSTEP(float, float); }
+#undef CSTEP
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

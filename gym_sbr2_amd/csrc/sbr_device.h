@@ -49,6 +49,8 @@ struct SbrPar {
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
     double x0[SBR_NX];
     double muH_etag;     // muH * eta_g
+    double t_ph[8];      // phase lengths t_cycle * t_ratio[k]                 (SBR_model_FB.py:18-27)
+    double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
     int32_t substeps, terminal, fill_rows, pad_;
 };
 
@@ -341,27 +343,34 @@ SBR_DEV void sbr_write_state(OutT* s, int st, double t_obs, const double (&x)[SB
 // ---------------------------------------------------------------------------------------------------
 // Terminal phases of the last call of an episode: settle (:2171-2262; v == vmax always, so the layer
 // system is linear and has the closed form below), draw + wastage (:2327-2393), idle (:2554-2597).
-SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX]) {
+// settle: layer concentrations after t_set (closed form, see above); returns Xf
+SBR_DEV double sbr_settle(const SbrPar& p, const double (&x)[SBR_NX], double t_set, double (&sx)[10]) {
     const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
-    const double vs = x[0], z = vs / p.settler_area;
-    const double t_set = p.t_settle * p.t_cycle;
+    const double z = x[0] / p.settler_area;
     const double a = p.settler_vmax / z * t_set, ea = exp(-a);
     // sX[9-j] = Xf e^-a sum_{m<=j} a^m/m!, sX[0] = 10 Xf - sum(others)
-    double sx[10], term = 1.0, partial = 0.0, others = 0.0;
+    double term = 1.0, partial = 0.0, others = 0.0;
 #pragma unroll
     for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= a / (double)(j + 1); }
 #pragma unroll
     for (int j = 1; j < 10; ++j) others += sx[j];
     sx[0] = 10.0 * xf - others;
-    const double t_after_draw = (c.t + t_set) + p.t_draw * p.t_cycle;
+    return xf;
+}
+
+// draw + wastage (:2327-2393 / sub_phases_FB.py:780-855): x becomes the reactor after the draw; returns Qw and, in
+// sx_eff, the sludge that left with the effluent (sum(sX[-m:-1]*layer_volume), which drops the last layer)
+SBR_DEV double sbr_draw(const SbrPar& p, double (&x)[SBR_NX], const double (&sx)[10], double xf, double& sx_eff) {
+    const double vs = x[0];
     const double layer_v = vs / 10;
     double resid_v = vs - p.Qeff;
     int m = (int)ceil(rint(p.Qeff / layer_v));        // python round() is half-to-even = rint
     m = m < 1 ? 1 : (m > 9 ? 9 : m);
     const int nl = 10 - m;                            // layers that stay
-    double wsum = 0.0;
+    double wsum = 0.0, se = 0.0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) if (i < nl) wsum = wsum + layer_v * sx[i];
+    for (int i = 0; i < 9; ++i) { if (i < nl) wsum = wsum + layer_v * sx[i]; else se = se + sx[i] * layer_v; }
+    sx_eff = se;
     double waste = wsum - p.biomass_setpoint * resid_v;
     double qw = __builtin_nan("");
     bool open = true;
@@ -382,6 +391,15 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
     x[0] = resid_v;
 #pragma unroll
     for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
+    return qw;
+}
+
+SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX]) {
+    const double t_set = p.t_settle * p.t_cycle;
+    double sx[10], sx_eff;
+    const double xf = sbr_settle(p, x, t_set, sx);
+    const double t_after_draw = (c.t + t_set) + p.t_draw * p.t_cycle;
+    const double qw = sbr_draw(p, x, sx, xf, sx_eff);
     // idle: one DO-PID update (So[-1] == So[-2] == x[8] after settle/draw => dcv = 0), then conversion only
     const double e = c.u_do - x[8];
     c.ie_do = c.ie_do + e * p.dt;
@@ -417,6 +435,100 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KL
         }
     }
     return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-cycle env SBR-v2: one PID-controlled phase (sub_phases_FB.py filling.sim_rxn :178-271 / rxn.sim_rxn :406-500).
+// Control intervals are the cells of linspace(t_start, t_end, n2), n2 = int((t_end-t_start)/(10 t_delta)); positional
+// PID on So with derivative action; interval 0 OVERWRITES Kla[0], which held the incoming bias, so intervals 1.. use the
+// controlled (clamped) Kla of interval 0 as bias (:219,:243); the integral restarts in every phase.  t_start/t_end
+// are wave-uniform.  Returns the last Kla; ksum = sum(Kla), n_iv = number of intervals.
+template <bool FILL>
+SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], double t_start, double t_end, double sp, double kla_in,
+                               const double (&ld)[SBR_NX], double& ksum, int& n_iv) {
+    const double t_delta = 0.002 / 24;                           // gym_SBR_env2.py:34
+    int n2 = (int)((t_end - t_start) / (t_delta * 10));
+    n2 = n2 < 2 ? 2 : (n2 > 100000 ? 100000 : n2);               // every wave terminates
+    n_iv = n2 - 1;
+    const double step = (t_end - t_start) / (double)(n2 - 1);    // numpy.linspace: i*step + start, last = stop
+    double so = x[8], so_prev = x[8], ie = 0.0, bias = kla_in, k = kla_in, sum = 0.0;
+    for (int i = 0; i < n_iv; ++i) {
+        const double g0 = (double)i * step + t_start;
+        const double g1 = (i + 1 == n2 - 1) ? t_end : (double)(i + 1) * step + t_start;
+        const double e = sp - so;
+        double dcv = 0.0;
+        if (i >= 1) { dcv = (so - so_prev) / p.cyc_dt; ie = ie + e * p.cyc_dt; }
+        k = p.cyc_Kc * e + p.cyc_KcI * ie + p.cyc_KcD * dcv + bias;
+        if (k > p.Kla_max) { k = p.Kla_max; ie = ie - e * p.cyc_dt; }
+        if (k < p.Kla_min) { k = p.Kla_min; ie = ie - e * p.cyc_dt; }
+        if (i == 0) bias = k;
+        sbr_rk4<FILL ? 1 : 2>(p, x, g1 - g0, p.substeps, k, 0.0, ld);
+        sum = sum + k;
+        so_prev = so; so = x[8];
+    }
+    ksum = sum;
+    return k;
+}
+
+// SbrEnv2.step (gym_SBR_env2.py:131-171) = SBR_model_FB.run (SBR_model_FB.py:8-295) + module_reward.py:4-51 for one env:
+// x is the start state in, the end-of-cycle state out; ld the influent with ld[0] = Qin/t_phs1; a[3] the clipped action.
+// obs3 = [Qeff, COD_eff, Snh_eff/30]; diag (SBR_NCYC_DIAG doubles) may be nullptr.
+SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double (&ld)[SBR_NX], double a0, double a1, double a2,
+                             double (&obs3)[3], double* diag, int diag_stride) {
+    const double t_delta = 0.002 / 24;
+    a0 = a0 < 0.0 ? 0.0 : (a0 > 1.0 ? 1.0 : a0); a1 = a1 < 0.0 ? 0.0 : (a1 > 1.0 ? 1.0 : a1);
+    a2 = a2 < 0.0 ? 0.0 : (a2 > 1.0 ? 1.0 : a2);
+    const double sp3 = a0 * 8, sp5 = a1 * 8, sp8 = a2 * 8;      // DO_setpoints[2], [4], [7]  (:184-186)
+    const double qin = p.WV - x[0];
+    double ks1, ks2, ks3, ks4, ks5, ks8;
+    int n1, n2, n3, n4, n5, n8;
+    double t_start = 0.0, t_end = 0.0 + p.t_ph[0];
+    double kl = sbr_cycle_phase<true>(p, x, t_start, t_end, 0.0, 0.0, ld, ks1, n1);
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[1];
+    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, 0.0, kl, ld, ks2, n2);
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[2];
+    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, sp3, kl, ld, ks3, n3);
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[3];
+    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, 0.0, kl, ld, ks4, n4);
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[4];
+    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, sp5, kl, ld, ks5, n5);
+    // settle
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[5];
+    double sx[10], sx_eff;
+    const double xf = sbr_settle(p, x, t_end - t_start, sx);
+    // draw; the effluent composition (cal_eq, sub_phases_FB.py:860-915) uses the PRE-draw state with its particulates
+    // scaled by the sludge carried out
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[6];
+    const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
+    const double qw = sbr_draw(p, x, sx, xf, sx_eff);
+    const double exi = xi * (1 / 0.75) * sx_eff / xf, exs = xs * (1 / 0.75) * sx_eff / xf, exbh = xbh * (1 / 0.75) * sx_eff / xf;
+    const double exba = xba * (1 / 0.75) * sx_eff / xf, exp_ = xp * (1 / 0.75) * sx_eff / xf;
+    const double snkj = x[10] + x[11] + x[12] + 0.08 * (exbh + exba) + 0.06 * (exp_ + exi);
+    const double ntot = x[9] + snkj;
+    const double ss_ = 0.75 * (exs + exi + exbh + exba + exp_);
+    const double bod5 = 0.25 * (x[2] + exs + (1 - 0.08) * (exbh + exba));
+    const double cod = x[2] + x[1] + exs + exi + exbh + exba + exp_;
+    const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
+    const double snh_eff = x[10], sno_eff = x[9];
+    // aerated idle from the drawn reactor, bias = last Kla of phase 5 (SBR_model_FB.py:258)
+    t_start = t_end + t_delta; t_end = t_start + p.t_ph[7];
+    sbr_cycle_phase<false>(p, x, t_start, t_end, sp8, kl, ld, ks8, n8);
+    // reward
+    const double td = 0.002 / 24;
+    const double ae3 = 1.32 * ks3 * td / ((double)n3 * td), ae5 = 1.32 * ks5 * td / ((double)n5 * td);
+    const double ae8 = (1.32 - qw) * ks8 * td / ((double)n8 * td);
+    const double ae = p.So_sat / (1.8 * 1000) * (ae3 + ae5 + ae8);
+    const double pe = (0.004 * qin + 0.05 * qw + 0.004 * p.Qeff);
+    const double me = 0.005 * 1.32 * 24 + 0.005 * 1.32 * 24;
+    const double oci = ae + pe + me;
+    obs3[0] = p.Qeff; obs3[1] = cod; obs3[2] = snh_eff / 30;
+    if (diag) {
+        const int st = diag_stride;
+        diag[0 * st] = qw; diag[1 * st] = eqi; diag[2 * st] = oci; diag[3 * st] = ntot; diag[4 * st] = cod; diag[5 * st] = snh_eff;
+        diag[6 * st] = bod5; diag[7 * st] = sno_eff; diag[8 * st] = ks3 / (double)n3; diag[9 * st] = ks5 / (double)n5;
+        diag[10 * st] = ks8 / (double)n8; diag[11 * st] = xf;
+    }
+    return (5 - oci) + (snh_eff < 4 ? 0.0 : -20.0);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,43 @@
+"""`SbrEnv2` - the reference's per-cycle class (gym_SBR/envs/gym_SBR_env2.py:58, id `SBR-v2`) with the same surface,
+backed by the batched HIP environment at N = 1:  reset() -> ndarray[3];  step(a[3]) -> (ndarray[3], float, True, {})."""
+import numpy as np
+import torch
+
+from ..cycle_env import SbrEnv2Vec
+from .sbr_os import _Box
+
+
+class SbrEnv2:
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, device=0, seed=None):
+        self.action_space = _Box([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])                       # :64
+        self.observation_space = _Box([0.5, 0, 0], [1.33, 2.5, 2])                       # :66 (as declared upstream)
+        self._vec = SbrEnv2Vec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64)
+        self._seed, self._episodes, self.reward = seed, 0, 0
+
+    def reset(self, rnd=None, scenario=None, influent=None, carry_over=False):
+        seed = (0 if self._seed is None else int(self._seed)) + self._episodes
+        self._episodes += 1
+        obs = self._vec.reset(seed=seed, scenario=None if scenario is None else [int(scenario)],
+                              rnd=None if rnd is None else np.asarray(rnd, dtype=np.float64)[None],
+                              influent=None if influent is None else np.asarray(influent, dtype=np.float64)[None],
+                              carry_over=carry_over)
+        return obs[0].cpu().numpy()
+
+    def step(self, action):
+        a = torch.tensor([[float(action[0]), float(action[1]), float(action[2])]], dtype=torch.float64)
+        obs, reward, _ = self._vec.step(a)
+        self.reward = float(reward[0].item())
+        return obs[0].cpu().numpy(), self.reward, True, {}
+
+    def diagnostics(self):
+        names = ["Qw", "EQI", "OCI", "Ntot_eff", "COD_eff", "Snh_eff", "BOD5_eff", "Sno_eff", "Kla3_mean", "Kla5_mean",
+                 "Kla8_mean", "Xf"]
+        return dict(zip(names, self._vec.diag[0].tolist()))
+
+    def render(self, mode="human"):
+        return None
+
+    def close(self):
+        self._vec.close()

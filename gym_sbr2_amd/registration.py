@@ -1,11 +1,10 @@
 """Environment ids.  The reference registers ten ids (gym_SBR/__init__.py:3-12); this build
-implements the hot path only, `SBROS-v1`.  The other nine raise a clear error (most of them cannot
+implements the hot path `SBROS-v1` and the per-cycle `SBR-v2`.  The other eight raise a clear error (most of them cannot
 run in the reference either)."""
 import importlib
 
-_REGISTRY = {"SBROS-v1": "gym_sbr2_amd.envs:SbrOS"}
-_NOT_BUILT = ["SBR-v0", "SBR-v1", "SBR-v2", "SBR-v4", "SBRCnt-v0", "SBRCnt-v1", "SBRCnt-v2", "SBRCntMA-v1",
-              "SBROS-v2"]
+_REGISTRY = {"SBROS-v1": "gym_sbr2_amd.envs:SbrOS", "SBR-v2": "gym_sbr2_amd.envs:SbrEnv2"}
+_NOT_BUILT = ["SBR-v0", "SBR-v1", "SBR-v4", "SBRCnt-v0", "SBRCnt-v1", "SBRCnt-v2", "SBRCntMA-v1", "SBROS-v2"]
 
 
 def registered_ids():
@@ -14,7 +13,7 @@ def registered_ids():
 
 def make(env_id, **kwargs):
     if env_id in _NOT_BUILT:
-        raise NotImplementedError("%s is outside the hot path this build accelerates (only SBROS-v1)" % env_id)
+        raise NotImplementedError("%s is outside the paths this build accelerates (SBROS-v1, SBR-v2)" % env_id)
     if env_id not in _REGISTRY:
         raise KeyError("unknown environment id %r; available: %s" % (env_id, registered_ids()))
     mod, cls = _REGISTRY[env_id].split(":")
@@ -30,7 +29,8 @@ def register_with_gym():
         except Exception:
             continue
         try:
-            reg.register(id="SBROS-v1", entry_point=_REGISTRY["SBROS-v1"])
+            for env_id, entry in _REGISTRY.items():
+                reg.register(id=env_id, entry_point=entry)
             done.append(name)
         except Exception:
             pass

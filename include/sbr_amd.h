@@ -91,6 +91,10 @@ typedef struct sbr_config {
     double act_DO_max, act_EC_max;                    /* action clipping :865-870, :901-906 */
     /* terminal phases                                            gym_SBR_oneshot.py:123-124, :2189-2218 */
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
+    /* per-cycle env SBR-v2 (gym_SBR_env2.py:32-48, SBR_model_FB.py:18-29): the eight phase fractions of the cycle and
+     * the positional DO-PID of sub_phases_FB.py:178-271 (DO_control_par = [Kc, tauI, delt, ..., tauD = [9]]) */
+    double t_ratio[8];
+    double cyc_Kc, cyc_tauI, cyc_tauD, cyc_dt;
     double x0[SBR_NX];                                /* episode start state :201-203 */
     /* integrator */
     int32_t substeps;          /* RK4 substeps per control interval (10 => h = dt) */
@@ -153,6 +157,25 @@ int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity);
  * call of an episode the settle/draw/idle phases.  Any of obs/state/reward/done may be NULL. */
 int sbr_step(sbr_env* env, const void* action, void* obs, void* state, void* reward, uint8_t* done,
              void* stream);
+
+/* ---- per-cycle environment `SBR-v2`: gym_SBR/envs/gym_SBR_env2.py::SbrEnv2, registered at
+ * gym_SBR/__init__.py:5.  One step() = one whole 12 h cycle: SBR_model_FB.run (SBR_model_FB.py:8-295) over the phase
+ * simulators of sub_phases_FB.py, reward module_reward.py:4-51.  A handle is used EITHER for sbr_reset/sbr_step OR for
+ * these two calls.
+ *   action [N][3] ActT in [0,1] (clipped): DO set-points of phases 3, 5 and 8 are action*8   gym_SBR_env2.py:133,184-186
+ *   obs    [N][3] OutT: reset: [V0 + 0.66, (COD0 + COD_in - 5145)/10, (Snh0 + Snh_in)/30]       :108-119
+ *                       step:  [Qeff, COD_eff, Snh_eff/30]                                      :164-169
+ *   diag   [N][SBR_NCYC_DIAG] float64 or NULL: Qw, EQI, OCI, effluent Ntot COD Snh BOD5 Sno, mean Kla of phases 3/5/8, Xf */
+#define SBR_NCYC_ACT 3
+#define SBR_NCYC_OBS 3
+#define SBR_NCYC_DIAG 12
+/* replaces SbrEnv2.reset(): influent draw (scenario NULL = 0 as at :104; rnd/influent/mask as in sbr_reset) and the reset
+ * observation.  carry_over != 0 keeps every env's current state as the start state of the next cycle (x0_new / IV_new,
+ * :152-153, disabled upstream at :85-97) instead of cfg.x0. */
+int sbr_cycle_reset(sbr_env* env, uint64_t seed, const int32_t* scenario, const double* rnd, const double* influent,
+                    const uint8_t* mask, int32_t carry_over, void* obs, void* stream);
+/* replaces SbrEnv2.step(action): every call is a complete episode (done is always true, :161). */
+int sbr_cycle_step(sbr_env* env, const void* action, void* obs, void* reward, double* diag, void* stream);
 
 /* fused rollout with an on-device uniform random policy (BASELINE.json configs[4]): n_steps step()
  * calls per env in ONE kernel, plant state held in registers; actions ~ U[0,act_DO_max] x

@@ -338,6 +338,101 @@ def run_episode(M, seed, actions, rnd_override=None):
     return rec
 
 
+# --------------------------------------------------------------------------- SBR-v2 (per-cycle env)
+def run_cycle_env(actions, seed):
+    """One `SbrEnv2` episode (= one 12 h cycle per step(), gym_SBR_env2.py:131-171) per action; records every phase
+    simulator call of SBR_model_FB.run (inputs, per-interval Kla, end state), the settler, the draw and the reward."""
+    from gym_SBR.envs import gym_SBR_env2 as E2
+    from gym_SBR.envs import sub_phases_FB as SP
+    calls = []
+    orig = {}
+
+    def spy_rxn(cls, name, kind):
+        f = getattr(cls, name)
+        orig[(cls, name)] = f
+
+        def inner(self, t_start, t_end, t_delta, x, Spar, Kpar, DOpar, *rest):
+            out = f(self, t_start, t_end, t_delta, x, Spar, Kpar, DOpar, *rest)
+            kla_in = rest[-1]
+            calls.append(dict(kind=kind, t_start=float(t_start), t_end=float(t_end), sp=float(DOpar[3]),
+                              x_in=np.array(x, dtype=np.float64), kla_in=float(kla_in),
+                              Kla=np.array(out[4], dtype=np.float64), x_end=np.array(out[1][-1], dtype=np.float64),
+                              n_rows_total=len(out[0])))
+            return out
+        setattr(cls, name, inner)
+    spy_rxn(SP.filling, "sim_rxn", 1)
+    spy_rxn(SP.rxn, "sim_rxn", 0)
+    f_set = SP.settling.sim_settling
+    f_draw = SP.drawing.sim_drawing
+    extra = {}
+
+    def spy_set(self, t_start, t_end, t_delta, x):
+        out = f_set(self, t_start, t_end, t_delta, x)
+        extra.setdefault("sX", []).append(np.array(out[2], dtype=np.float64))
+        extra.setdefault("Xf", []).append(float(out[3]))
+        return out
+
+    def spy_draw(self, t_start, t_end, t_delta, x, sX, Xf, Qeff, bs):
+        sx_in = np.array(sX, dtype=np.float64)       # the draw mutates its sX argument through a view
+        out = f_draw(self, t_start, t_end, t_delta, x, sX, Xf, Qeff, bs)
+        extra.setdefault("x_after_draw", []).append(np.array(out[1], dtype=np.float64))
+        extra.setdefault("Qw", []).append(float(out[2]))
+        extra.setdefault("EQI", []).append(float(out[5]))
+        extra.setdefault("eff", []).append(np.array(out[6], dtype=np.float64))
+        extra.setdefault("sX_at_draw", []).append(sx_in)
+        return out
+    SP.settling.sim_settling = spy_set
+    SP.drawing.sim_drawing = spy_draw
+    real_randn = np.random.randn
+    box = {}
+
+    def spy_randn(*a):
+        r = real_randn(*a)
+        box["rnd"] = np.array(r)
+        return r
+    rec = {"actions": np.asarray(actions, dtype=np.float64)}
+    per = {k: [] for k in ("rnd", "reset_state", "influent_mixed", "state", "reward", "phase_first", "phase_count")}
+    try:
+        np.random.seed(seed)
+        env = E2.SbrEnv2()
+        for a in actions:
+            np.random.randn = spy_randn
+            with contextlib.redirect_stdout(io.StringIO()):
+                st0 = env.reset()
+            np.random.randn = real_randn
+            first = len(calls)
+            with contextlib.redirect_stdout(io.StringIO()):
+                st, r, done, _ = env.step(np.array(a, dtype=np.float64))
+            assert done is True
+            per["rnd"].append(box["rnd"]); per["reset_state"].append(np.array(st0, dtype=np.float64))
+            per["influent_mixed"].append(np.array(E2.influent_mixed, dtype=np.float64))
+            per["state"].append(np.array(st, dtype=np.float64)); per["reward"].append(float(r))
+            per["phase_first"].append(first); per["phase_count"].append(len(calls) - first)
+    finally:
+        np.random.randn = real_randn
+        for (cls, name), f in orig.items():
+            setattr(cls, name, f)
+        SP.settling.sim_settling = f_set
+        SP.drawing.sim_drawing = f_draw
+    for k, v in per.items():
+        rec[k] = np.asarray(v)
+    for k, v in extra.items():
+        rec[k] = np.asarray(v)
+    nmax = max(len(c["Kla"]) for c in calls)
+    kla = np.full((len(calls), nmax), np.nan)
+    for i, c in enumerate(calls):
+        kla[i, :len(c["Kla"])] = c["Kla"]
+    rec["ph_Kla"] = kla
+    rec["ph_n_intervals"] = np.asarray([len(c["Kla"]) for c in calls], dtype=np.int64)
+    for f in ("kind", "t_start", "t_end", "sp", "kla_in", "n_rows_total"):
+        rec["ph_" + f] = np.asarray([c[f] for c in calls], dtype=np.float64)
+    rec["ph_x_in"] = np.asarray([c["x_in"] for c in calls])
+    rec["ph_x_end"] = np.asarray([c["x_end"] for c in calls])
+    rec["DO_control_par"] = np.asarray(E2.DO_control_par, dtype=np.float64)
+    rec["t_ratio"] = np.asarray(E2.t_ratio, dtype=np.float64)
+    return rec
+
+
 def phase_constants(M):
     return dict(T1_end=np.float64(M.t_memory1[-1]), T3_0=np.float64(M.t_memory3[0]),
                 T3_end=np.float64(M.t_memory3[-1]), T4_end=np.float64(M.t_memory4[-1]),
@@ -383,6 +478,11 @@ def main():
         np.savez_compressed(os.path.join(out, "sbros_%s.npz" % name), **rec)
         print("%-14s calls=%d intervals=%d return=%.16g Qw=%.16g" % (
             name, rec["n_calls"], len(rec["iv_kind"]), rec["episode_return"], rec.get("term_Qw", np.nan)))
+    acts = np.array([[0.25, 0.25, 0.25], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.6, 0.1, 0.9], [1.7, -0.3, 0.5]])   # last: clipped
+    rec = run_cycle_env(acts, seed=11)
+    np.savez_compressed(os.path.join(out, "sbrv2_cycles.npz"), **rec)
+    print("SBR-v2: %d cycles, phases per cycle %s, rewards %s" % (len(acts), rec["phase_count"].tolist(),
+                                                                  np.round(rec["reward"], 6).tolist()))
     print("wrote fixtures to", out)
 
 

@@ -30,6 +30,8 @@ typedef struct {
     double EC_min, EC_max, Kc_EC, tauI_EC, tauD_EC, EC_conc;
     double act_DO_max, act_EC_max;
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
+    double t_ratio[8];
+    double cyc_Kc, cyc_tauI, cyc_tauD, cyc_dt;
     double x0[NX];
     int32_t substeps, out_f64, terminal, act_f64;
 } sbro_params;
@@ -73,6 +75,9 @@ void sbro_default_params(sbro_params* p) {
     p->act_DO_max = 8; p->act_EC_max = 15;
     /* :123-124, :2189, :2211 */
     p->biomass_setpoint = 2700; p->Qeff = 0.66; p->settler_area = (1.25 / 2) * (1.25 / 2); p->settler_vmax = 474;
+    static const double tr[8] = {4.2 / 100, 8.3 / 100, 37.5 / 100, 31.2 / 100, 2.1 / 100, 8.3 / 100, 2.1 / 100, 6.3 / 100};
+    memcpy(p->t_ratio, tr, sizeof tr);
+    p->cyc_Kc = 5.0; p->cyc_tauI = 0.00035; p->cyc_tauD = 0.005; p->cyc_dt = 0.02 / 24;    /* gym_SBR_env2.py:48 */
     static const double x0[NX] = {0.6161484733495801, 30, 0.571098000538576, 1440.01157895393, 31.254221999137,
                                   2599.2714348941, 168.915006750837, 551.901552960823, 2.16607843793004,
                                   13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
@@ -500,4 +505,144 @@ void sbro_batch_rollout(const sbro_params* p, int64_t n, sbro_env* envs, int64_t
         }
         if (returns) returns[i] = acc;
     }
+}
+
+
+/* =================================================================================== per-cycle env SBR-v2
+ * SbrEnv2.step (gym_SBR_env2.py:131-171) = SBR_model_FB.run (SBR_model_FB.py:8-295): five PID-controlled phases
+ * (sub_phases_FB.py filling.sim_rxn :178-271, rxn.sim_rxn :406-500), settle (:716-775, closed form), draw + effluent
+ * quality (:780-915), aerated idle, reward module_reward.py:4-51.  RK4 with p->substeps substeps per control interval. */
+#define NCYC_DIAG 12     /* qw, EQI, OCI, eff[1..5] = Ntot COD Snh BOD5 Sno, mean Kla of phases 3, 5, 8, Xf */
+
+/* numpy.linspace(a, b, n)[i] */
+static double lin(double a, double b, int n, int i) {
+    if (i == n - 1) return b;
+    const double step = (b - a) / (double)(n - 1);
+    return (double)i * step + a;
+}
+
+/* one phase: positional PID with bias Kla[0]; interval 0 overwrites Kla[0], so later intervals use the controlled
+ * value of interval 0 as bias (sub_phases_FB.py:219,243).  Returns the last Kla; *ksum gets sum(Kla), *n_iv the count. */
+static double cycle_phase(const sbro_params* p, double* x, double t_start, double t_end, double t_delta, double sp,
+                          double kla_in, const double* loading, double* ksum, int* n_iv_out, double* kla_log) {
+    const int n2 = (int)((t_end - t_start) / (t_delta * 10));
+    const int n_iv = n2 - 1;
+    double so = x[8], so_prev = x[8], ie = 0, bias = kla_in, k = kla_in, sum = 0;
+    for (int i = 0; i < n_iv; ++i) {
+        const double g0 = lin(t_start, t_end, n2, i), g1 = lin(t_start, t_end, n2, i + 1);
+        const double e = sp - so;
+        double dcv = 0;
+        if (i >= 1) { dcv = (so - so_prev) / p->cyc_dt; ie = ie + e * p->cyc_dt; }
+        k = p->cyc_Kc * e + p->cyc_Kc / p->cyc_tauI * ie + p->cyc_Kc * p->cyc_tauD * dcv + bias;
+        if (k > p->Kla_max) { k = p->Kla_max; ie = ie - e * p->cyc_dt; }
+        if (k < p->Kla_min) { k = p->Kla_min; ie = ie - e * p->cyc_dt; }
+        if (i == 0) bias = k;
+        rk4_span(p, loading ? 1 : 2, x, g1 - g0, p->substeps, k, 0, loading);
+        sum = sum + k;
+        if (kla_log) kla_log[i] = k;
+        so_prev = so; so = x[8];
+    }
+    *ksum = sum; *n_iv_out = n_iv;
+    return k;
+}
+
+/* x: start state in, end-of-cycle state out.  influent[14] ([0] is replaced by Qin/t_phs1).  action[3] in [0,1].
+ * state3 = [Qeff, COD_eff, Snh_eff/30]; diag[NCYC_DIAG]; kla_log (6 x 256 doubles, phases 1..5 and 8) may be NULL. */
+void sbro_cycle_step(const sbro_params* p, double* x, const double* influent, const double* action, double* state3,
+                     double* reward, double* diag, double* kla_log) {
+    const double t_delta = 0.002 / 24;
+    double a[3], sp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph[8], loading[NX];
+    for (int j = 0; j < 3; ++j) a[j] = action[j] < 0 ? 0 : (action[j] > 1 ? 1 : action[j]);
+    sp[2] = a[0] * 8; sp[4] = a[1] * 8; sp[7] = a[2] * 8;
+    for (int j = 0; j < 8; ++j) tph[j] = p->t_cycle * p->t_ratio[j];
+    const double iv = x[0], qin = p->WV - iv;
+    memcpy(loading, influent, sizeof loading);
+    loading[0] = qin / (p->t_cycle * p->t_ratio[0]);
+    double ksum[6], klast = 0;
+    int niv[6];
+    double t_start = 0, t_end = 0 + tph[0];
+    klast = cycle_phase(p, x, t_start, t_end, t_delta, sp[0], 0.0, loading, &ksum[0], &niv[0], kla_log ? kla_log : 0);
+    for (int ph = 1; ph <= 4; ++ph) {
+        t_start = t_end + t_delta; t_end = t_start + tph[ph];
+        klast = cycle_phase(p, x, t_start, t_end, t_delta, sp[ph], klast, 0, &ksum[ph], &niv[ph], kla_log ? kla_log + 256 * ph : 0);
+    }
+    const double kla5_last = klast;
+    /* settle */
+    t_start = t_end + t_delta; t_end = t_start + tph[5];
+    const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
+    const double vs = x[0], z = vs / p->settler_area;
+    const double aa = p->settler_vmax / z * (t_end - t_start), ea = exp(-aa);
+    double sx[10], term = 1.0, partial = 0.0, others = 0.0;
+    for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= aa / (j + 1); }
+    for (int j = 1; j < 10; ++j) others += sx[j];
+    sx[0] = 10.0 * xf - others;
+    /* draw */
+    t_start = t_end + t_delta; t_end = t_start + tph[6];
+    const double layer_v = vs / 10;
+    double resid_v = vs - p->Qeff;
+    int m = (int)ceil(nearbyint(p->Qeff / layer_v));
+    if (m < 1) m = 1;
+    if (m > 9) m = 9;
+    double sx_eff = 0;
+    for (int i = 10 - m; i < 9; ++i) sx_eff = sx_eff + sx[i] * layer_v;          /* sum(sX[-m:-1]*layer_volume) */
+    double xe[NX];
+    memcpy(xe, x, sizeof xe);
+    xe[0] = p->Qeff;
+    for (int i = 3; i <= 7; ++i) xe[i] = xe[i] * (1 / 0.75) * sx_eff / xf;
+    double w[10], rs[10], wsum = 0;
+    for (int i = 0; i < 10 - m; ++i) { w[i] = layer_v * sx[i]; rs[i] = sx[i]; }
+    for (int i = 0; i < 10 - m; ++i) wsum = wsum + w[i];
+    double waste = wsum - p->biomass_setpoint * resid_v, qw = NAN;
+    for (int i = 0; i < 10 - m; ++i) {
+        const double rest = waste - w[i];
+        if (rest > 0) { waste = rest; rs[i] = 0; w[i] = 0; resid_v -= layer_v; }
+        else { qw = waste / (rs[i] - p->biomass_setpoint); w[i] = w[i] - qw * rs[i]; resid_v -= qw; rs[i] = w[i] / (layer_v - qw); break; }
+    }
+    wsum = 0;
+    for (int i = 0; i < 10 - m; ++i) wsum = wsum + w[i];
+    const double sx2 = wsum / resid_v;
+    /* effluent quality on xe (cal_eq :860-915) */
+    const double snkj = xe[10] + xe[11] + xe[12] + 0.08 * (xe[5] + xe[6]) + 0.06 * (xe[7] + xe[3]);
+    const double ntot = xe[9] + snkj;
+    const double ss_ = 0.75 * (xe[4] + xe[3] + xe[5] + xe[6] + xe[7]);
+    const double bod5 = 0.25 * (xe[2] + xe[4] + (1 - 0.08) * (xe[5] + xe[6]));
+    const double cod = xe[2] + xe[1] + xe[4] + xe[3] + xe[5] + xe[6] + xe[7];
+    const double eqi = (2 * ss_ + 1 * cod + 30 * snkj + 10 * xe[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
+    const double snh_eff = xe[10], sno_eff = xe[9];
+    x[0] = resid_v;
+    for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
+    /* aerated idle from the drawn reactor, bias = last Kla of phase 5 */
+    t_start = t_end + t_delta; t_end = t_start + tph[7];
+    cycle_phase(p, x, t_start, t_end, t_delta, sp[7], kla5_last, 0, &ksum[5], &niv[5], kla_log ? kla_log + 256 * 5 : 0);
+    /* reward */
+    const double td = 0.002 / 24;
+    const double ae3 = 1.32 * ksum[2] * td / (niv[2] * td);
+    const double ae5 = 1.32 * ksum[4] * td / (niv[4] * td);
+    const double ae8 = (1.32 - qw) * ksum[5] * td / (niv[5] * td);
+    const double ae = p->So_sat / (1.8 * 1000) * (ae3 + ae5 + ae8);
+    const double pe = (0.004 * qin + 0.05 * qw + 0.004 * p->Qeff);
+    const double me = 0.005 * 1.32 * 24 + 0.005 * 1.32 * 24;
+    const double oci = ae + pe + me;
+    *reward = (5 - oci) + (snh_eff < 4 ? 0 : -20);
+    state3[0] = p->Qeff; state3[1] = cod; state3[2] = snh_eff / 30;
+    if (diag) {
+        diag[0] = qw; diag[1] = eqi; diag[2] = oci; diag[3] = ntot; diag[4] = cod; diag[5] = snh_eff; diag[6] = bod5;
+        diag[7] = sno_eff; diag[8] = ksum[2] / niv[2]; diag[9] = ksum[4] / niv[4]; diag[10] = ksum[5] / niv[5]; diag[11] = xf;
+    }
+}
+
+/* reset observation of SbrEnv2 (gym_SBR_env2.py:108-119): sums of start state and influent */
+void sbro_cycle_reset_state(const double* x0, const double* influent, double* state3) {
+    double tot[NX];
+    for (int i = 0; i < NX; ++i) tot[i] = x0[i] + influent[i];
+    const double cod = tot[1] + tot[2] + tot[3] + tot[4] + tot[5] + tot[6] + tot[7];
+    state3[0] = tot[0]; state3[1] = (cod - 5145) / 10; state3[2] = tot[10] / 30;
+}
+
+void sbro_batch_cycle_step(const sbro_params* p, int64_t n, double* x /* [n][14] */, const double* influent /* [n][14] */,
+                           const double* action /* [n][3] */, double* state3, double* reward, double* diag, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        sbro_cycle_step(p, x + i * NX, influent + i * NX, action + 3 * i, state3 + 3 * i, reward + i,
+                        diag ? diag + NCYC_DIAG * i : 0, 0);
 }

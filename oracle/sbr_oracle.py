@@ -19,6 +19,8 @@ class Params(C.Structure):
         "WV IV dt t_delta t_cycle T_fill T3_0 T3_end T4_end T5_end t_settle t_draw "
         "So_sat Kla_min Kla_max Kc_DO tauI_DO tauD_DO EC_min EC_max Kc_EC tauI_EC tauD_EC EC_conc "
         "act_DO_max act_EC_max biomass_setpoint Qeff settler_area settler_vmax").split()] + [
+        ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
+        ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
         ("terminal", C.c_int32), ("act_f64", C.c_int32)]
 
@@ -190,3 +192,44 @@ def rk4(kind, x, span, n, kla, ec=0.0, loading=None, params=None):
     lib().sbro_rk4(C.byref(p), C.c_int(kind), _p(x), C.c_double(span), C.c_int(n), C.c_double(kla), C.c_double(ec),
                    _p(ld))
     return x
+
+
+NCYC_DIAG = 12   # qw, EQI, OCI, Ntot, COD, Snh, BOD5, Sno (effluent), mean Kla of phases 3, 5, 8, Xf
+
+
+class OracleCycleBatch:
+    """N per-cycle (`SBR-v2`) environments stepped by the C oracle: one step() = one whole 12 h cycle."""
+
+    def __init__(self, n, params=None, nthreads=1):
+        self.n, self.nthreads = int(n), int(nthreads)
+        self.p = params if params is not None else default_params()
+        self.x = np.tile(np.array(self.p.x0[:], dtype=np.float64), (self.n, 1))
+        self.influent = np.zeros((self.n, NX))
+
+    def reset(self, influent, carry_over=False):
+        self.influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64).copy()
+        if not carry_over:
+            self.x = np.tile(np.array(self.p.x0[:], dtype=np.float64), (self.n, 1))
+        st = np.empty((self.n, 3))
+        for i in range(self.n):
+            lib().sbro_cycle_reset_state(_p(self.x[i]), _p(self.influent[i]), _p(st[i]))
+        return st
+
+    def step(self, action):
+        action = np.ascontiguousarray(np.broadcast_to(action, (self.n, 3)), dtype=np.float64)
+        st, rew, diag = np.empty((self.n, 3)), np.empty(self.n), np.empty((self.n, NCYC_DIAG))
+        self.x = np.ascontiguousarray(self.x)
+        lib().sbro_batch_cycle_step(C.byref(self.p), C.c_int64(self.n), _p(self.x), _p(self.influent), _p(action), _p(st),
+                                    _p(rew), _p(diag), C.c_int(self.nthreads))
+        return st, rew, diag
+
+    def step_logged(self, i, action):
+        """One env, with the per-interval Kla of the six PID phases (6 x 256, NaN-padded)."""
+        log = np.full((6, 256), np.nan)
+        st, rew, diag = np.empty(3), np.empty(1), np.empty(NCYC_DIAG)
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        x = np.ascontiguousarray(self.x[i]).copy()
+        lib().sbro_cycle_step(C.byref(self.p), _p(x), _p(np.ascontiguousarray(self.influent[i])), _p(a), _p(st), _p(rew),
+                              _p(diag), _p(log))
+        self.x[i] = x
+        return st, float(rew[0]), diag, log

@@ -61,8 +61,13 @@ def test_default_config_is_the_reference():
     from oracle import sbr_oracle as O
     p = O.default_params()
     assert C.sizeof(p) == C.sizeof(cfg)
-    for name, _ in _capi.SbrConfig._fields_[:-5]:
-        assert getattr(p, name) == getattr(cfg, name), name
+    for name, ctype in _capi.SbrConfig._fields_:
+        a, b = getattr(p, name), getattr(cfg, name)
+        if hasattr(a, "__len__"):
+            assert list(a) == list(b), name
+        elif name != "out_f64":          # the oracle always returns float64
+            assert a == b, name
+    assert list(cfg.t_ratio) == c["t_ratio"].tolist() and (cfg.cyc_Kc, cfg.cyc_tauI, cfg.cyc_tauD, cfg.cyc_dt) == (5.0, 0.00035, 0.005, 0.02 / 24)
 
 
 def test_packaged_influent_tables_are_the_captured_ones():
@@ -86,7 +91,7 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
         gym_sbr2_amd.SbrOSVec(8)
     with pytest.raises(_capi.SbrError):
         gym_sbr2_amd.make("SBROS-v1")
-    assert gym_sbr2_amd.registered_ids() == ["SBROS-v1"]
+    assert gym_sbr2_amd.registered_ids() == ["SBR-v2", "SBROS-v1"]
 
 
 def test_product_never_imports_the_oracle():

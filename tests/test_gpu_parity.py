@@ -537,6 +537,72 @@ def test_multi_cycle_carry_over_against_oracle(G, tables):
     env.close()
 
 
+def test_cycle_env_sbr_v2_against_oracle_and_reference(G, tables):
+    """`SBR-v2`: one step() = one whole 12 h cycle in one launch.  The five reference cycles (float64
+    actions incl. an out-of-range one), then 256 envs with random influent/scenarios/actions against the C oracle,
+    then a carried-over second cycle."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    g = golden("sbrv2_cycles")
+    n = len(g["actions"])
+    env = G.SbrEnv2Vec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    obs0 = _np(env.reset(rnd=g["rnd"])).copy()
+    assert np.abs(obs0 - g["reset_state"]).max() < 1e-11                  # sums of start state and influent
+    obs, rew, done = env.step(torch.from_numpy(g["actions"]).cuda())
+    obs, rew, diag = _np(obs), _np(rew), _np(env.diag)
+    x, _ = env.get_state()
+    last = g["ph_x_end"][g["phase_first"] + 5]
+    assert np.all(_np(done) == 1)
+    assert gate(_np(x).T, last).max() <= 0.1                               # oracle: 0.018 (RK4 vs the reference's LSODA)
+    assert np.abs(rew - g["reward"]).max() < 1e-6                          # oracle: 3.2e-8
+    assert np.allclose(obs, g["state"], rtol=1e-6, atol=1e-7)
+    assert np.abs(diag[:, 0] / g["Qw"] - 1).max() < 1e-5 and np.abs(diag[:, 1] / g["EQI"] - 1).max() < 1e-6
+    # effluent Ntot, COD, Snh, BOD5, Sno: mixed tolerance of the gate (Sno/Snh decay to ~0 in some cycles, where a purely
+    # relative error is meaningless): 1e-5 |ref| + 1e-5 * 20
+    assert np.all(np.abs(diag[:, 3:8] - g["eff"][:, 1:]) <= 1e-5 * np.abs(g["eff"][:, 1:]) + 2e-4)
+    ora = O.OracleCycleBatch(n)
+    from oracle.sbr_ref import influent_mix
+    ora.reset(np.stack([influent_mix(means[0], stds[0], g["rnd"][c]) for c in range(n)]))
+    ost, orew, odiag = ora.step(g["actions"])
+    assert gate(_np(x).T, ora.x).max() < 1e-6 and np.abs(rew - orew).max() < 1e-11 and np.abs(obs - ost).max() < 1e-9
+    assert np.allclose(diag, odiag, rtol=1e-10, atol=1e-12)
+    env.close()
+    # a bigger batch: float32 I/O, all eight scenarios, random actions incl. out-of-range ones
+    n = 256
+    rs = np.random.RandomState(8)
+    scen = (np.arange(n) % 8).astype(np.int32)
+    z = rs.randn(n, 48)
+    a = rs.uniform(-0.2, 1.2, (n, 3)).astype(np.float32)
+    env = G.SbrEnv2Vec(n)
+    ora = O.OracleCycleBatch(n, nthreads=8)
+    infl = O.OracleBatch(n).mix(means, stds, scen, z)
+    o0 = _np(env.reset(scenario=scen, rnd=z)); oo0 = ora.reset(infl)
+    assert np.allclose(o0, oo0, rtol=2e-6, atol=1e-6)
+    obs, rew, _ = env.step(torch.from_numpy(a).cuda())
+    ost, orew, odiag = ora.step(a.astype(np.float64))
+    x, ctrl = env.get_state()
+    clean = (_np(ctrl)[_capi.C_STATUS].astype(int) & _capi.ST_NEAR_POLE) == 0
+    assert clean.sum() > n // 2 and gate(_np(x).T[clean], ora.x[clean]).max() < 1e-6
+    assert np.allclose(_np(rew)[clean], orew[clean], rtol=2e-6, atol=1e-5) and np.allclose(_np(obs)[clean], ost[clean], rtol=2e-6, atol=1e-4)
+    assert np.allclose(_np(env.diag)[clean], odiag[clean], rtol=1e-9, atol=1e-11)
+    # second cycle carried over from the end state of the first
+    z2 = rs.randn(n, 48)
+    env.reset(scenario=scen, rnd=z2, carry_over=True); ora.reset(O.OracleBatch(n).mix(means, stds, scen, z2), carry_over=True)
+    obs, rew, _ = env.step(torch.from_numpy(a).cuda()); ost, orew, _ = ora.step(a.astype(np.float64))
+    x, ctrl = env.get_state()
+    clean &= (_np(ctrl)[_capi.C_STATUS].astype(int) & _capi.ST_NEAR_POLE) == 0
+    assert clean.sum() > n // 4 and gate(_np(x).T[clean], ora.x[clean]).max() < 1e-6
+    assert np.allclose(_np(rew)[clean], orew[clean], rtol=2e-6, atol=1e-5)
+    env.close()
+    # the reference-shaped single env
+    e1 = G.make("SBR-v2")
+    s0 = e1.reset(rnd=g["rnd"][0])
+    s1, r1, d1, info = e1.step(g["actions"][0])
+    assert s0.shape == (3,) and np.abs(s0 - g["reset_state"][0]).max() < 1e-11 and d1 is True and info == {}
+    assert abs(r1 - g["reward"][0]) < 1e-6 and np.allclose(s1, g["state"][0], rtol=1e-6) and abs(e1.diagnostics()["Qw"] / g["Qw"][0] - 1) < 1e-5
+    e1.close()
+
+
 def test_reference_shaped_single_env(G):
     """The N = 1 class keeps the reference's surface: reset() -> (list9, list9); step -> 5-tuple (:438, :1273)."""
     e = golden("sbros_const_2_5")
@@ -559,5 +625,5 @@ def test_reference_shaped_single_env(G):
     obs2 = env.reset(rnd=e["rnd"], carry_over=True)          # second cycle from where the first one ended
     assert len(obs2[0]) == 9 and obs2[0] != obs[0]
     with pytest.raises(NotImplementedError):
-        G.make("SBR-v2")
+        G.make("SBR-v4")
     env.close()
