@@ -14,6 +14,8 @@ phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
                        episode returns per episode, inside the timed region); per-GPU work is fixed => weak scaling.
     config1            4096 envs per GPU, deterministic influent (64 wavefronts: cannot fill 1024 SIMDs; a parity case)
     config5            65536 envs per GPU, fused on-device random-policy rollout (sbr_rollout), 463 calls per launch
+    cycle              65536 envs per GPU of the per-cycle env SBR-v2: one launch = one whole cycle of 528
+                       control intervals; a "step" is then one cycle and `value` is still control intervals per second
 Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase) runs INSIDE the timed region and is
 not counted as steps.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
 """
@@ -58,12 +60,67 @@ def cpu_baseline(n_envs=4096, calls=100):
                       % (n_envs, calls, cores)}
 
 
+INTERVALS_PER_CYCLE = 528      # 24 + 48 + 223 + 186 + 11 + 36 control intervals (tests/golden/sbrv2_cycles.npz)
+
+
+def bench_cycle(args, torch, dist, world, rank, local_rank, dev):
+    """SBR-v2: every step is reset (influent draw) + one whole cycle, for all envs of this rank."""
+    from gym_sbr2_amd import SbrEnv2Vec
+    n_local = args.envs_per_gpu or 65536
+    n_global = n_local * world
+    env = SbrEnv2Vec(n_local, device=local_rank, first_env_id=rank * n_local)
+    scenario = ((torch.arange(n_local, device=dev) + rank * n_local) % 8).to(torch.int32)
+    gen = torch.Generator(device=dev); gen.manual_seed(4321 + rank)
+    pool = torch.rand(16, n_local, 3, device=dev, generator=gen)
+    steps = max(1, min(args.steps, 64)) if args.steps == 1852 else args.steps       # default K is sized for config2
+
+    def one(k):
+        env.reset(seed=k, scenario=scenario)
+        env.step(pool[k & 15], want_diag=False)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for k in range(max(1, min(args.warmup, 3))):
+        one(k)
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for k in range(steps):
+        one(100 + k)
+    e1.record(); fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    per_launch_s = e0.elapsed_time(e1) * 1e-3 / steps
+    achieved = n_local * INTERVALS_PER_CYCLE * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
+    out = {"metric": "env-steps/sec (batched)", "value": n_global * steps * INTERVALS_PER_CYCLE / elapsed, "unit": "env-steps/s",
+           "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "SBR-v2 per-cycle env (SURVEY.md 8f-3): %d envs/GPU, one step = reset + one whole 12 h cycle = %d "
+                                  "control intervals of RK4 (10 substeps); value counts control intervals" % (n_local, INTERVALS_PER_CYCLE),
+                      "envs_per_gpu": n_local, "envs_total": n_global, "cycles_per_s": n_global * steps / elapsed,
+                      "kernel": "k_cycle<float,float> (+ k_cycle_reset)"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                        "traffic": None, "avg_launch_us": per_launch_s * 1e6,
+                        "note": "513 algorithmic bytes per control interval by the per-step convention; the fused kernel actually "
+                                "moves one load and one store of the plant per cycle - it is fp64-VALU-bound"}}
+    env.close()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1852)       # four episodes
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config5"])
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config5", "cycle"])
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -85,6 +142,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
 
+    if args.workload == "cycle":
+        return bench_cycle(args, torch, dist, world, rank, local_rank, dev)
     n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
     n_global = n_local * world
     first = rank * n_local
