@@ -550,7 +550,7 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.cyc_Kc = c.cyc_Kc; p.cyc_KcI = c.cyc_Kc / c.cyc_tauI; p.cyc_KcD = c.cyc_Kc * c.cyc_tauD; p.cyc_dt = c.cyc_dt;
     p.substeps = c.substeps; p.terminal = c.terminal;
     p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
-    p.pad_ = 0;
+    p.reward_kind = c.reward_kind;
 }
 
 template <typename OutT, typename ActT>
@@ -592,7 +592,7 @@ int sbr_default_config(sbr_config* c) {
                                       13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
                                       3.790463057094611};
     memcpy(c->x0, x0, sizeof x0);
-    c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->act_f64 = 0;
+    c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->reward_kind = 0; c->act_f64 = 0;
     return SBR_OK;
 }
 
@@ -616,6 +616,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     const sbr_config& c = e->cfg;
     std::string bad;
     if (c.substeps < 1 || c.substeps > 10000) bad = "substeps out of range";
+    if (c.reward_kind < 0 || c.reward_kind > 1) bad = "reward_kind must be 0 (EQI/OCI) or 1 (G2ANET)";
     if (!(c.dt > 0) || !(c.t_delta > 0)) bad = "dt and t_delta must be positive";
     else {
         const int rows = (int)(c.t_delta / c.dt + 0.5);

@@ -51,7 +51,7 @@ struct SbrPar {
     double muH_etag;     // muH * eta_g
     double t_ph[8];      // phase lengths t_cycle * t_ratio[k]                 (SBR_model_FB.py:18-27)
     double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
-    int32_t substeps, terminal, fill_rows, pad_;
+    int32_t substeps, terminal, fill_rows, reward_kind;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -310,6 +310,16 @@ SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)
     return (1 - (eqi2 * eqi2 + oci * oci)) / 473;
 }
 
+// module_reward_continuous_G2ANET.py:4-45 (cfg.reward_kind = 1): piecewise-linear in Ss, So, Sno, Snh of the end state
+SBR_DEV double sbr_reward_g2anet(const double (&x)[SBR_NX]) {
+    const double ss = x[2], so = x[8], sno = x[9], snh = x[10];
+    const double r_ec = ss < 0 ? 1.0 : -(ss - 0) / (10 - 0) + 1;
+    const double r_e = so < 1.5 ? 0.0 : -(1 / (8 - 1.5)) * (so - 8) + 0;
+    const double r_sno = sno < 4 ? 1.0 : -(sno - 4) / (20 - 4) + 1;
+    const double r_snh = snh < 4 ? 1.0 : -(snh - 4) / (20 - 4) + 1;
+    return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) / 10;
+}
+
 SBR_DEV double sbr_clip1(double v) { return v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v); }
 
 // obs_DO ++ obs_EC :1027-1114 (normalisers :150-156, xdot scales :1069-1076) and state = [t, x] / x_1_state
@@ -423,7 +433,7 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX],
                                double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw) {
     sbr_hist_apply(c, hist);
-    const double r = sbr_reward(p, c, hist, x);
+    const double r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x);     // wave-uniform choice
     t_obs = c.t;
     dn = false;
     if (c.t >= p.T5_end) {                                               // :1122

@@ -100,6 +100,8 @@ typedef struct sbr_config {
     int32_t substeps;          /* RK4 substeps per control interval (10 => h = dt) */
     int32_t out_f64;           /* 0: obs/state/reward are float32; 1: float64 */
     int32_t terminal;          /* 1: run settle/draw/idle on the done step (reference behaviour) */
+    int32_t reward_kind;       /* 0: EQI/OCI reward of module_reward_EQIOCI.py (SBROS-v1); 1: the piecewise-linear reward of
+                                  module_reward_continuous_G2ANET.py:4-45 (used by the variant gym_SBR_oneshot_copy.py:17,614) */
     int32_t act_f64;           /* 0: sbr_step reads float32 actions; 1: float64.  A finished env ignores step()
                                   until sbr_reset either way (the reference leaves resetting to the caller) */
 } sbr_config;

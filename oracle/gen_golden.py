@@ -478,6 +478,13 @@ def main():
         np.savez_compressed(os.path.join(out, "sbros_%s.npz" % name), **rec)
         print("%-14s calls=%d intervals=%d return=%.16g Qw=%.16g" % (
             name, rec["n_calls"], len(rec["iv_kind"]), rec["episode_return"], rec.get("term_Qw", np.nan)))
+    from gym_SBR.envs.module_reward_continuous_G2ANET import sbr_reward as g2anet
+    kk = np.load(os.path.join(out, "rhs_kat.npz"))
+    Xr = kk["X"].copy()
+    Xr[:6, 2] = [-1.0, 0.0, 5.0, 10.0, 25.0, 9.999]; Xr[6:12, 8] = [0.0, 1.5, 1.49, 8.0, 3.0, 12.0]        # around every kink
+    Xr[12:18, 9] = [3.999, 4.0, 20.0, 30.0, 0.0, -1.0]; Xr[18:24, 10] = [3.999, 4.0, 20.0, 30.0, 0.0, -1.0]
+    np.savez_compressed(os.path.join(out, "reward_g2anet_kat.npz"), X=Xr,
+                        reward=np.asarray([g2anet(x, None, False, 0) for x in Xr], dtype=np.float64))
     acts = np.array([[0.25, 0.25, 0.25], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.6, 0.1, 0.9], [1.7, -0.3, 0.5]])   # last: clipped
     rec = run_cycle_env(acts, seed=11)
     np.savez_compressed(os.path.join(out, "sbrv2_cycles.npz"), **rec)

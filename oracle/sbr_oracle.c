@@ -33,7 +33,7 @@ typedef struct {
     double t_ratio[8];
     double cyc_Kc, cyc_tauI, cyc_tauD, cyc_dt;
     double x0[NX];
-    int32_t substeps, out_f64, terminal, act_f64;
+    int32_t substeps, out_f64, terminal, reward_kind, act_f64;
 } sbro_params;
 
 /* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
@@ -83,7 +83,7 @@ void sbro_default_params(sbro_params* p) {
                                   13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
                                   3.790463057094611};
     memcpy(p->x0, x0, sizeof x0);
-    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->act_f64 = 0;
+    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->reward_kind = 0; p->act_f64 = 0;
 }
 
 int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }
@@ -356,9 +356,20 @@ static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
     e->status = status_bits(p, e->x, e->status);
 }
 
+/* module_reward_continuous_G2ANET.py:4-45: piecewise-linear in Ss, So, Sno, Snh of the end state */
+double sbro_reward_g2anet(const double* x) {
+    const double ss = x[2], so = x[8], sno = x[9], snh = x[10];
+    const double r_ec = ss < 0 ? 1 : -(ss - 0) / (10 - 0) + 1;
+    const double r_e = so < 1.5 ? 0 : -(1 / (8 - 1.5)) * (so - 8) + 0;
+    const double r_sno = sno < 4 ? 1 : -(sno - 4) / (20 - 4) + 1;
+    const double r_snh = snh < 4 ? 1 : -(snh - 4) / (20 - 4) + 1;
+    return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) / 10;
+}
+
 /* module_reward_EQIOCI.py:4-115 */
 static double reward_of(const sbro_params* p, const sbro_env* e) {
     const double* x = e->x;
+    if (p->reward_kind == 1) return sbro_reward_g2anet(x);
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
     const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
     const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);

@@ -22,7 +22,7 @@ class Params(C.Structure):
         ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("act_f64", C.c_int32)]
+        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32)]
 
 
 class Env(C.Structure):

@@ -56,7 +56,7 @@ def test_default_config_is_the_reference():
     assert [cfg.muH, cfg.Ks, cfg.Koh, cfg.Kno, cfg.bH, cfg.eta_g, cfg.eta_h, cfg.kh, cfg.Kx, cfg.muA, cfg.Knh, cfg.bA,
             cfg.Koa, cfg.ka] == k["Kpar"].tolist()
     assert np.array_equal(np.array(cfg.x0[:]), golden("sbros_const_2_5")["x0_init"])
-    assert (cfg.substeps, cfg.terminal, cfg.out_f64, cfg.act_f64) == (10, 1, 0, 0)
+    assert (cfg.substeps, cfg.terminal, cfg.out_f64, cfg.act_f64, cfg.reward_kind) == (10, 1, 0, 0, 0)
     # the oracle's parameter block has the same layout and the same defaults
     from oracle import sbr_oracle as O
     p = O.default_params()

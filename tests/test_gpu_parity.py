@@ -363,6 +363,42 @@ def test_ragged_batch_sizes(G, tables, n):
     env.close()
 
 
+def test_g2anet_reward_option(G, tables):
+    """cfg.reward_kind = 1: same plant, the piecewise-linear reward of module_reward_continuous_G2ANET.py.
+    The device reward of every call must equal the reference function evaluated on the device's own end state."""
+    from gym_sbr2_amd import _capi
+    k = golden("reward_g2anet_kat")
+    cfg = _capi.default_config(); cfg.reward_kind = 1
+    n = len(k["X"])
+    env = G.SbrOSVec(n, out_dtype=torch.float64, config=cfg)
+    p = O.default_params(); p.reward_kind = 1
+    ora = O.OracleBatch(n, params=p)
+    means, stds = tables
+    z = np.random.RandomState(1).randn(n, 48); scen = (np.arange(n) % 8).astype(np.int32)
+    env.reset(scenario=scen, rnd=z); ora.reset(ora.mix(means, stds, scen, z))
+    a = np.column_stack([np.full(n, 2.0), np.full(n, 5.0)]).astype(np.float32)
+    for c in range(60):
+        _, _, r, _ = env.step(torch.from_numpy(a).cuda()); _, _, orr, _ = ora.step(a.astype(np.float64))
+        assert np.abs(_np(r) - orr).max() < 1e-12
+    env.close()
+    # known answers: inject the fixture's states (they straddle every kink of the reward; a few sit ON a Monod pole,
+    # e.g. Snh = -1, and turn NaN within one interval - there the device and the reference function must both be NaN)
+    cfg.terminal = 0                                   # no settle/draw/idle: the inspected state is the reward's state
+    env = G.SbrOSVec(n, out_dtype=torch.float64, config=cfg)
+    x = k["X"].T.copy(); ctrl = np.zeros((_capi.NCTRL, n)); ctrl[_capi.C_T] = 0.45
+    env.set_state(x, ctrl)
+    import ctypes as C
+    fn = O.lib().sbro_reward_g2anet; fn.restype = C.c_double
+    _, _, r, _ = env.step(torch.zeros(n, 2))
+    x1, _ = env.get_state()
+    want = np.array([fn(O._p(np.ascontiguousarray(v))) for v in _np(x1).T])
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isfinite(_np(r)), finite) and finite.sum() >= 90
+    assert np.abs(_np(r)[finite] - want[finite]).max() < 1e-14
+    assert (_np(env.status())[~finite] & _capi.ST_NONFINITE).all()      # and the status flag says so
+    env.close()
+
+
 def test_status_flags_report_leaving_the_physical_domain(G):
     """The reference silently returns garbage once a concentration is driven to a Monod pole; the library reproduces
     the numbers but raises sticky flags.  States are injected with set_state and one call is taken."""
@@ -601,6 +637,43 @@ def test_cycle_env_sbr_v2_against_oracle_and_reference(G, tables):
     assert s0.shape == (3,) and np.abs(s0 - g["reset_state"][0]).max() < 1e-11 and d1 is True and info == {}
     assert abs(r1 - g["reward"][0]) < 1e-6 and np.allclose(s1, g["state"][0], rtol=1e-6) and abs(e1.diagnostics()["Qw"] / g["Qw"][0] - 1) < 1e-5
     e1.close()
+
+
+def _sharded_worker(rank, world, n_global, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)         # one GPU on this box: gloo carries the gather
+    try:
+        from gym_sbr2_amd.sharding import ShardedSbrOS, gather_returns
+        sh = ShardedSbrOS(n_global, rank=rank, world=world, device=0, out_dtype=torch.float32)
+        sh.reset(seed=5)
+        sh.rollout(120, policy_seed=9)
+        local = sh.env.episode_returns().to(torch.float32).cpu()
+        full = gather_returns(local, n_global)
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
+        sh.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_sharded_by_global_env_id(G, tmp_path):
+    """BASELINE.json configs[3] rehearsed on one GPU: two processes, each a contiguous shard of the global env ids with
+    its own handle; the single collective (all-gather of episode returns) must give every rank the vector a single
+    process computes - influent noise, scenarios and the random policy are keyed by the GLOBAL env id."""
+    import socket
+    import torch.multiprocessing as mp
+    n_global, world = 1000, 2                                             # ragged: 500 + 500, not multiples of 64
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sharded_worker, args=(world, n_global, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / ("rank%d.npy" % r)) for r in range(world)]
+    env = G.SbrOSVec(n_global)
+    env.reset(seed=5, scenario=(np.arange(n_global) % 8).astype(np.int32))
+    env.rollout(120, policy_seed=9)
+    single = _np(env.episode_returns().to(torch.float32))
+    assert np.array_equal(got[0], got[1]) and got[0].shape == (n_global,)
+    assert np.array_equal(got[0], single)                                 # bit-identical: same kernel, same per-env inputs
+    env.close()
 
 
 def test_reference_shaped_single_env(G):

@@ -334,3 +334,15 @@ def test_control_rounding_noise_is_amplified_to_gate_level_by_the_closed_loop(ta
     assert np.median(g) < 1e-7 and np.percentile(g, 99) < 1e-4 and g.max() <= 1.0
     assert g.max() > 1e-6                                  # i.e. >= 1e10 ulp: the amplification is real
     assert np.abs(runs[0][2] - runs[1][2]).max() < 1e-9    # no clamp/anti-windup branch flipped (that would be ~1e-4)
+
+
+def test_g2anet_reward_known_answers():
+    """cfg.reward_kind = 1: module_reward_continuous_G2ANET.py, values from the reference function itself on 96 states
+    that straddle every kink (Ss = 0, 10; So = 1.5; Sno, Snh = 4)."""
+    import ctypes as C
+    k = golden("reward_g2anet_kat")
+    fn = O.lib().sbro_reward_g2anet
+    fn.restype = C.c_double
+    got = np.array([fn(O._p(np.ascontiguousarray(x))) for x in k["X"]])
+    assert np.array_equal(got, k["reward"])
+    assert len(set(np.round(k["reward"], 6))) > 40
