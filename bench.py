@@ -34,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md:
 CALLS_PER_EPISODE = 463
 
 
-def cpu_baseline(n_envs=4096, calls=100):
+def cpu_baseline(n_envs=16384, calls=463):
     """The CPU oracle (a C port of the same algorithm: RK4, fp64, OpenMP over envs) timed on this box's host cores, on a
     bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
     import numpy as np
@@ -48,7 +48,7 @@ def cpu_baseline(n_envs=4096, calls=100):
     rs = np.random.RandomState(0)
     acts = [np.column_stack([rs.uniform(0, 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
     best = 0.0
-    for _ in range(3):                 # best of three: shared hosts are noisy
+    for _ in range(3):                 # best of three: shared hosts are noisy (about 0.5 s each: 7.6 M env-steps)
         b.reset(infl)
         b.step(acts[0], want_obs=False)
         t0 = time.perf_counter()
@@ -63,7 +63,7 @@ def cpu_baseline(n_envs=4096, calls=100):
 INTERVALS_PER_CYCLE = 528      # 24 + 48 + 223 + 186 + 11 + 36 control intervals (tests/golden/sbrv2_cycles.npz)
 
 
-def bench_cycle(args, torch, dist, world, rank, local_rank, dev):
+def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
     """SBR-v2: every step is reset (influent draw) + one whole cycle, for all envs of this rank."""
     from gym_sbr2_amd import SbrEnv2Vec
     n_local = args.envs_per_gpu or 65536
@@ -112,7 +112,7 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev):
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def main():
@@ -124,6 +124,17 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # Native libraries print to fd 1 (RCCL writes a five-line version banner when a communicator is created); the contract is
+    # ONE JSON line on stdout, so fd 1 points at stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
 
     import torch
     import torch.distributed as dist
@@ -139,11 +150,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)        # nccl == RCCL on ROCm
+    force_dist = os.environ.get("SBR_BENCH_FORCE_DIST") == "1"      # rehearse the RCCL calls with a single rank
+    if world > 1 or force_dist:
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)    # nccl == RCCL on ROCm
 
     if args.workload == "cycle":
-        return bench_cycle(args, torch, dist, world, rank, local_rank, dev)
+        return bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit)
     n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
     n_global = n_local * world
     first = rank * n_local
@@ -170,7 +186,7 @@ def main():
         # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync):
         # the per-env returns, collated over ranks by the one collective of the path (configs[3])
         ret = env.episode_returns(out=ret64).to(torch.float32)
-        state["returns"] = gather_returns(ret, n_global) if world > 1 else ret
+        state["returns"] = gather_returns(ret, n_global) if (world > 1 or force_dist) else ret
         env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
 
     acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0}
@@ -203,7 +219,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -218,7 +234,7 @@ def main():
     run(args.steps, record=True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,11 +286,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     env.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -17,11 +17,12 @@
 #include <string>
 #include <vector>
 
+#ifndef SBR_BLOCK
+#define SBR_BLOCK 256     // threads per workgroup of the stepping kernels: four waves, one per SIMD.  Measured at N = 65536:
+                          // 64 -> 23.0 us, 128 -> 22.8, 256 -> 22.65 per k_step launch (fewer workgroups to dispatch)
+#endif
 #include "sbr_device.h"
 
-#ifndef SBR_BLOCK
-#define SBR_BLOCK 64      // one wavefront per workgroup (an experiment build uses 32: half-filled waves)
-#endif
 #define SBR_RESET_BLOCK 256     // k_reset stages 84 KiB of tables in LDS: one block per CU, so make it four waves
 static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB
 
@@ -253,10 +254,10 @@ template <typename OutT, typename ActT, int W>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
-    __shared__ double park[SBR_NPARK * 64];
+    __shared__ double park[SBR_NPARK * SBR_BLOCK];
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= b.n) return;
-    double* my = park + threadIdx.x;
+    double* my = park + threadIdx.x;          // slot j of this lane: my[j * SBR_BLOCK]
     double x[SBR_NX];
     SbrCtl c;
     load_x(b, i, x);
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
     c.kla_last = CTRL(R_RING0 + ring_slot(k0, SBR_KLA_HIST - 1));
     const double kla_before = c.kla_last;
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * 64] = CTRL(R_RING0 + ring_slot(k0, j));
-    my[9 * 64] = CTRL(R_RET); my[10 * 64] = meta0;
-    SbrX6Lds x6{my + 11 * 64};
+    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_slot(k0, j));
+    my[9 * SBR_BLOCK] = CTRL(R_RET); my[10 * SBR_BLOCK] = meta0;
+    SbrX6Lds x6{my + 11 * SBR_BLOCK};
     x6.put(x);
     double t_obs = p.t_cycle, r = 0.0;
     bool dn = true;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
         sbr_run_intervals(p, c, x, a0, a1, x6);
 #pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * 64];
+        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * SBR_BLOCK];
         hist[SBR_KLA_HIST - 1] = kla_before;
         x6.get(xa6);
         r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             CTRL(R_RING0 + ring_slot(k0, 0)) = c.knew[0];
             if (c.n_new > 1) CTRL(R_RING0 + ring_slot(k0, 1)) = c.knew[1];
         }
-        meta_unpack(my[10 * 64], steps, status, was_done);
-        CTRL(R_RET) = my[9 * 64] + r;
+        meta_unpack(my[10 * SBR_BLOCK], steps, status, was_done);
+        CTRL(R_RET) = my[9 * SBR_BLOCK] + r;
         CTRL(R_META) = meta_pack(steps + 1.0, status | c.st_new, dn);
         if (b.trace != nullptr && i < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + i;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_stats(const double* __restrict__ 
         mx = fmax(mx, __shfl_xor(mx, off, 64));
         cnt += __shfl_xor(cnt, off, 64);
     }
-    if (threadIdx.x == 0 && cnt > 0.0) {
+    if ((threadIdx.x & 63) == 0 && cnt > 0.0) {      // lane 0 of EVERY wave of the workgroup publishes its wave's partials
         atomicAdd(out4 + 0, s);
         atomic_min_f64(out4 + 1, mn);
         atomic_max_f64(out4 + 2, mx);

@@ -6,6 +6,8 @@ seen, and are written next to each assertion.  GPU vs oracle differences come on
 and summation order (both sides are fp64 RK4 with identical inputs: the oracle is always fed exactly the action
 values the device sees - float64 where the test compares with the golden vectors, float32-rounded elsewhere).
 """
+import os
+
 import numpy as np
 import pytest
 from conftest import EPISODES, gate, golden, obs_tolerance
@@ -24,7 +26,9 @@ def G():
     import gym_sbr2_amd
     from gym_sbr2_amd import _capi
     assert torch.cuda.is_available(), "these tests need the GPU box"
-    lib = _capi.load(build_if_missing=False)      # the in-tree .so must be the thing that runs
+    lib = _capi.load()                            # builds it with hipcc if the snapshot lacks it; never a fallback
+    assert _capi.library_path().endswith(os.path.join("gym_sbr2_amd", "lib", "libsbr_amd.so"))   # the in-tree .so is what runs
+    assert any("libsbr_amd.so" in l for l in open("/proc/self/maps"))
     assert lib.sbr_device_count() >= 1
     return gym_sbr2_amd
 
