@@ -71,9 +71,50 @@ SBR_DEV double sbr_rcp(double d) {
 // Process rates :1660-1685, combination :1731-1755.  The reference's ten quotients are evaluated with SEVEN shared
 // reciprocals: So/(Koh+So) and Koh/(Koh+So) share one, and (Xs/Xbh)/(Kx + Xs/Xbh) is written Xs/(Kx*Xbh + Xs).
 // Equal coefficients are factored (nu2_1 = nu2_2, nu4_4 = nu4_5, ...).  Parity is to tolerance, not bitwise.
-SBR_DEV void sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double kla, double (&r)[SBR_NX]) {
+template <bool WITH_V>
+SBR_DEV double sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double kla, double (&r)[SBR_NX]) {
     const double ss = x[2], xs = x[4], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10], snd = x[11],
                  xnd = x[12];
+#ifndef SBR_BATCH_RCP
+#define SBR_BATCH_RCP 1
+#endif
+#if SBR_BATCH_RCP
+    // v_rcp_f64 issues in ~32 cycles on gfx950 (8 FMA slots; measured: 392 + 28 x 32 cycles = the 1.02 us of a substep), so the
+    // seven reciprocals are taken from ONE: R = 1/(d1 d2 ... d7), then 1/dk = R x (product of the others), peeled off with
+    // two multiplications each (Montgomery's trick): 18 multiplications + 1 reciprocal instead of 7 reciprocals.  Rounding
+    // grows to ~7 ulp (parity bounds are >= 1e-11 relative); the product (~1e10) cannot over- or underflow for finite states.
+    const double d1 = p.Ks + ss, d2 = p.Koh + so, d3 = p.Kno + sno, d4 = p.Knh + snh, d5 = p.Koa + so;
+    const double d6 = __builtin_fma(p.Kx, xbh, xs), d7 = xs;
+#if SBR_BATCH_RCP == 2
+    // two independent chains (4 + 3 denominators): one more reciprocal, but half the serial dependency depth
+    const double q2 = d1 * d2, q3 = q2 * d3;
+    double Ra = sbr_rcp(q3 * d4);
+    const double rd = Ra * q3; Ra = Ra * d4;
+    const double rc = Ra * q2; Ra = Ra * d3;
+    const double rb = Ra * d1, ra = Ra * d2;
+    const double rv = WITH_V ? sbr_rcp(x[0]) : 0.0;
+    const double s2 = d5 * d6;
+    double Rb = sbr_rcp(s2 * d7);
+    const double rg = Rb * s2; Rb = Rb * d7;
+    const double re = Rb * d6, rf = Rb * d5;
+#else
+    const double p2 = d1 * d2, p3 = p2 * d3, p4 = p3 * d4, p5 = p4 * d5, p6 = p5 * d6;
+    double R, rv = 0.0;
+    if (WITH_V) {                        // dosing / fill: 1/V for the dilution terms rides in the same batch
+        const double p7 = p6 * d7;
+        R = sbr_rcp(p7 * x[0]);
+        rv = R * p7; R = R * x[0];
+    } else {
+        R = sbr_rcp(p6 * d7);
+    }
+    const double rg = R * p6; R = R * d7;
+    const double rf = R * p5; R = R * d6;
+    const double re = R * p4; R = R * d5;
+    const double rd = R * p3; R = R * d4;
+    const double rc = R * p2; R = R * d3;
+    const double rb = R * d1, ra = R * d2;
+#endif
+#else
     const double ra = sbr_rcp(p.Ks + ss);
     const double rb = sbr_rcp(p.Koh + so);
     const double rc = sbr_rcp(p.Kno + sno);
@@ -81,6 +122,8 @@ SBR_DEV void sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double k
     const double re = sbr_rcp(p.Koa + so);
     const double rf = sbr_rcp(__builtin_fma(p.Kx, xbh, xs));
     const double rg = sbr_rcp(xs);
+    const double rv = WITH_V ? sbr_rcp(x[0]) : 0.0;
+#endif
     const double m_so = so * rb;                     // So/(Koh+So)
     const double inox = (p.Koh * rb) * (sno * rc);   // Koh/(Koh+So) * Sno/(Kno+Sno)
     const double g = (ss * ra) * xbh;                // Ss/(Ks+Ss) * Xbh
@@ -105,6 +148,7 @@ SBR_DEV void sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double k
     r[11] = rho8 - rho6;
     r[12] = __builtin_fma(p.n12_45, s45, -rho8);
     r[13] = p.n13_1 * rho1 + p.n13_2 * rho2 + p.n13_3 * rho3 + p.n13_6 * rho6;
+    return rv;                           // 1/V if WITH_V
 }
 
 // Right-hand sides.  KIND 0: reaction_dxdt :1658-1787 (dosing ec, dilution ec/V)
@@ -115,14 +159,14 @@ template <int KIND>
 SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, double ec, const double (&ld)[SBR_NX],
                      double (&d)[SBR_NX]) {
     double r[SBR_NX];
-    sbr_conversion(p, x, kla, r);
+    const double rv = sbr_conversion<(KIND == 0 || KIND == 1)>(p, x, kla, r);
     if (KIND == 0) {
-        const double q = ec * sbr_rcp(x[0]);
+        const double q = ec * rv;
         d[0] = ec;
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (i == 2 ? (p.EC_conc - x[i]) : (-x[i]));
     } else if (KIND == 1) {
-        const double q = ld[0] * sbr_rcp(x[0]);
+        const double q = ld[0] * rv;
         d[0] = ld[0];
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (ld[i] - x[i]);
