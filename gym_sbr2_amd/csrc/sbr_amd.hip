@@ -743,6 +743,7 @@ int sbr_set_trace(sbr_env* e, double* buf, int64_t n_envs, int64_t capacity) {
 
 int sbr_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done, void* stream) {
     if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_step: NULL env or action");
+    HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
     if (e->cfg.out_f64) {
         if (e->cfg.act_f64) launch_step<double, double>(e, action, obs, state, reward, done, st);
@@ -775,6 +776,7 @@ int sbr_cycle_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const do
 
 int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, double* diag, void* stream) {
     if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_cycle_step: NULL env or action");
+    HIP_TRY(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
 #define CSTEP(T, A) hipLaunchKernelGGL((k_cycle<T, A>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
@@ -787,6 +789,7 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
 
 int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
     if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
+    HIP_TRY(e, hipSetDevice(e->device));
     hipLaunchKernelGGL(k_rollout, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
                        policy_seed, returns, actions_out);
     HIP_TRY(e, hipGetLastError());

@@ -403,6 +403,30 @@ def test_g2anet_reward_option(G, tables):
     env.close()
 
 
+def test_step_is_hip_graph_capturable(G):
+    """sbr_step neither allocates nor synchronises, so a sequence of steps can be captured in a HIP graph and replayed;
+    the replayed plant must be bit-identical to stepping eagerly."""
+    n, k = 4096, 64
+    scen = (np.arange(n) % 8).astype(np.int32)
+    acts = torch.rand(k, n, 2, device="cuda") * torch.tensor([2.5, 15.0], device="cuda")
+    a_env, b_env = G.SbrOSVec(n), G.SbrOSVec(n)
+    a_env.reset(seed=2, scenario=scen); b_env.reset(seed=2, scenario=scen)
+    a_env.step(acts[0]); b_env.step(acts[0])                                   # warm up (module load) outside the capture
+    a_env.reset(seed=2, scenario=scen); b_env.reset(seed=2, scenario=scen)
+    torch.cuda.synchronize()
+    graph = a_env.capture_steps([acts[j] for j in range(k)])                  # capturing does not execute
+    for _ in range(3):
+        graph.replay()
+    for _ in range(3):
+        for j in range(k):
+            b_env.step(acts[j])
+    torch.cuda.synchronize()
+    xa, ca = a_env.get_state(); xb, cb = b_env.get_state()
+    assert torch.equal(xa, xb) and torch.equal(ca, cb) and int(ca[20].max().item()) == 3 * k
+    assert torch.equal(a_env.obs, b_env.obs) and torch.equal(a_env.reward, b_env.reward)
+    a_env.close(); b_env.close()
+
+
 def test_status_flags_report_leaving_the_physical_domain(G):
     """The reference silently returns garbage once a concentration is driven to a Monod pole; the library reproduces
     the numbers but raises sticky flags.  States are injected with set_state and one call is taken."""
