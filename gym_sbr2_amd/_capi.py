@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 23, 10
+NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
 NTRACE = 19          # t, x[14], Kla, EC, reward, done per traced env and call
@@ -16,9 +16,11 @@ NTRACE = 19          # t, x[14], Kla, EC, reward, done per traced env and call
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
 C_KLA_LAST = C_KLA_HIST0 + KLA_HIST - 1
-C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
-                                              C_KLA_LAST + 5)
+C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS, C_KLA_SUM = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
+                                                         C_KLA_LAST + 5, C_KLA_LAST + 6)
 ST_NEGATIVE, ST_NEAR_POLE, ST_NONFINITE = 1, 2, 4     # SBR_ST_* bits of the status row
+# cfg.reward_kind: module_reward_EQIOCI.py (SBROS-v1) / module_reward_continuous_G2ANET.py / module_reward_continuous.py
+REWARD_KINDS = {"eqi_oci": 0, "g2anet": 1, "oci": 2}
 
 _DBL = ("Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka "
         "WV IV dt t_delta t_cycle T_fill T3_0 T3_end T4_end T5_end t_settle t_draw "

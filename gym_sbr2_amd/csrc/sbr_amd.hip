@@ -49,10 +49,11 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i, const double (&x)[SBR_NX]) {
 //  * the Kla history is a RING: the value of the j-th interval since reset sits in slot (j-1) % 10, where the interval
 //    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten;
 //  * steps, status bits and the done flag share one row (meta = steps*16 + status*2 + done);
-//  * rows only read when tauD != 0 (So[-2], Sno[-2]) or only at the end of an episode (Qw) come last.
+//  * rows only read when tauD != 0 (So[-2], Sno[-2]), only at the end of an episode (Qw) or only by the operating-cost
+//    reward (the running sum of Kla) come last.
 // Per env-step the step kernel reads 18 rows and writes 11 (232 B) instead of 20 + 24 (352 B).
 enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_RING0,
-       R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_NROWS };
+       R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_KSUM, R_NROWS };
 #define CTRL(f) b.ctrl[(int64_t)(f) * b.n + i]
 
 SBR_DEV long long ring_k(const SbrPar& p, double t) {       // intervals since reset, from the running time
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
 #pragma unroll
     for (int j = 0; j < SBR_KLA_HIST; ++j) v[SBR_C_KLA_HIST0 + j] = hist[j];
     v[SBR_C_QW] = CTRL(R_QW); v[SBR_C_RETURN] = CTRL(R_RET); v[SBR_C_STEPS] = steps;
-    v[SBR_C_DONE] = done ? 1.0 : 0.0; v[SBR_C_STATUS] = (double)status;
+    v[SBR_C_DONE] = done ? 1.0 : 0.0; v[SBR_C_STATUS] = (double)status; v[SBR_C_KLA_SUM] = CTRL(R_KSUM);
     if (only_row >= 0) {
 #pragma unroll
         for (int r = 0; r < SBR_NCTRL; ++r) if (r == only_row) out[i] = v[r];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
     CTRL(R_SNO_M1) = IN(SBR_C_SNO_M1); CTRL(R_SNO_M2) = IN(SBR_C_SNO_M2);
     CTRL(R_IE_DO) = IN(SBR_C_IE_DO); CTRL(R_IE_EC) = IN(SBR_C_IE_EC); CTRL(R_EC_LAST) = IN(SBR_C_EC_LAST);
     store_ring(b, i, ring_k(p, t), hist);
-    CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN);
+    CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN); CTRL(R_KSUM) = IN(SBR_C_KLA_SUM);
     CTRL(R_META) = meta_pack(IN(SBR_C_STEPS), (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0);
 #undef IN
 }
@@ -228,6 +229,9 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     store_ctl(b, i, c);
     store_ring(b, i, ring_k(p, c.t), hist);          // k = 0: logical order = slot order
     CTRL(R_RET) = 0.0; CTRL(R_META) = meta_pack(0.0, sbr_status_bits(p, x), false); CTRL(R_QW) = 0.0;
+    double ksum = 0.0;                               // python's sum() over the list [0, k]*126, left to right
+    for (int j = 0; j < p.fill_rows / 2; ++j) ksum = ksum + kla;
+    CTRL(R_KSUM) = ksum;
     if (obs) {   // volume blend of influent and post-fill state, :346-361
         double xr[SBR_NX];
 #pragma unroll
@@ -250,11 +254,11 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // doubles per lane) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip
 // through L2/HBM, and the RK4 loop keeps its registers.  Slot j of lane l is at park[j*64 + l] (conflict-free).
 #define SBR_NPARK (SBR_KLA_HIST - 1 + 2 + SBR_NXD)
-template <typename OutT, typename ActT, int W>
+template <typename OutT, typename ActT, int W, bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
-    __shared__ double park[SBR_NPARK * SBR_BLOCK];
+    __shared__ double park[(SBR_NPARK + (OCI ? 1 : 0)) * SBR_BLOCK];
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= b.n) return;
     double* my = park + threadIdx.x;          // slot j of this lane: my[j * SBR_BLOCK]
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
     for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_slot(k0, j));
     my[9 * SBR_BLOCK] = CTRL(R_RET); my[10 * SBR_BLOCK] = meta0;
     SbrX6Lds x6{my + 11 * SBR_BLOCK};
+    if (OCI) my[SBR_NPARK * SBR_BLOCK] = CTRL(R_KSUM);    // only this reward keeps the running sum of Kla
     x6.put(x);
     double t_obs = p.t_cycle, r = 0.0;
     bool dn = true;
@@ -284,7 +289,9 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
         for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * SBR_BLOCK];
         hist[SBR_KLA_HIST - 1] = kla_before;
         x6.get(xa6);
-        r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
+        double ksum = OCI ? my[SBR_NPARK * SBR_BLOCK] : 0.0;
+        r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum);
+        if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
         // (wave-uniform test: no lane of the wave changed them)
         const bool inert_moved = (x[0] != v0) || (x[1] != si0) || (x[3] != xi0);
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
 }
 
 // ------------------------------------------------------------------------------------------- rollout
+template <bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
     c.so_m2 = CTRL(R_SO_M2); c.sno_m2 = CTRL(R_SNO_M2);
     load_ring(b, i, ring_k(p, c.t), hist);
     c.kla_last = hist[SBR_KLA_HIST - 1];
-    double ret = CTRL(R_RET), steps, qw = CTRL(R_QW);
+    double ret = CTRL(R_RET), steps, qw = CTRL(R_QW), ksum = OCI ? CTRL(R_KSUM) : 0.0;
     int status; bool finished;
     meta_unpack(CTRL(R_META), steps, status, finished);
     double acc = 0.0;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
         bool dn;
         sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
-        const double r = sbr_finish_step(p, c, hist, x, xa6, t_obs, dn, qw);
+        const double r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum);
         acc += r; ret += r; steps += 1.0; status |= c.st_new;
         if (dn) finished = true;
     }
@@ -359,6 +367,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
     // (the idle phase's extra Kla does not advance t; k_export reads with the same rule)
     store_ring(b, i, ring_k(p, c.t), hist);
     CTRL(R_RET) = ret; CTRL(R_META) = meta_pack(steps, status, finished); CTRL(R_QW) = qw;
+    if (OCI) CTRL(R_KSUM) = ksum;                     // like k_step: only this reward maintains the row
     if (returns) returns[i] = acc;
 }
 // ------------------------------------------------------------------------------------------- per-cycle env (SBR-v2)
@@ -554,16 +563,22 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.reward_kind = c.reward_kind;
 }
 
+template <typename OutT, typename ActT, bool OCI>
+static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
+                          hipStream_t st) {
+    const dim3 grid((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK));
+    if (e->n > 98304)      // more than 1.5 waves per SIMD on 1024 SIMDs: the two-waves-per-SIMD build wins
+        hipLaunchKernelGGL((k_step<OutT, ActT, 2, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
+                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+    else
+        hipLaunchKernelGGL((k_step<OutT, ActT, 1, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
+                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+}
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                         hipStream_t st) {
-    const dim3 grid((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK));
-    if (e->n > 98304)      // more than 1.5 waves per SIMD on 1024 SIMDs: the two-waves-per-SIMD build wins
-        hipLaunchKernelGGL((k_step<OutT, ActT, 2>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
-                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
-    else
-        hipLaunchKernelGGL((k_step<OutT, ActT, 1>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
-                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+    if (e->cfg.reward_kind == 2) launch_step_k<OutT, ActT, true>(e, action, obs, state, reward, done, st);
+    else launch_step_k<OutT, ActT, false>(e, action, obs, state, reward, done, st);
 }
 
 extern "C" {
@@ -617,7 +632,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     const sbr_config& c = e->cfg;
     std::string bad;
     if (c.substeps < 1 || c.substeps > 10000) bad = "substeps out of range";
-    if (c.reward_kind < 0 || c.reward_kind > 1) bad = "reward_kind must be 0 (EQI/OCI) or 1 (G2ANET)";
+    if (c.reward_kind < 0 || c.reward_kind > 2) bad = "reward_kind must be 0 (EQI/OCI), 1 (G2ANET) or 2 (operating cost)";
     if (!(c.dt > 0) || !(c.t_delta > 0)) bad = "dt and t_delta must be positive";
     else {
         const int rows = (int)(c.t_delta / c.dt + 0.5);
@@ -790,8 +805,12 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
 int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
     if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
     HIP_TRY(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_rollout, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
-                       policy_seed, returns, actions_out);
+    if (e->cfg.reward_kind == 2)
+        hipLaunchKernelGGL(k_rollout<true>, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
+                           policy_seed, returns, actions_out);
+    else
+        hipLaunchKernelGGL(k_rollout<false>, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
+                           policy_seed, returns, actions_out);
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

@@ -367,6 +367,23 @@ SBR_DEV double sbr_reward_g2anet(const double (&x)[SBR_NX]) {
     return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) / 10;
 }
 
+// module_reward_continuous.py:4-65 (cfg.reward_kind = 2, the reward of SbrEnv3/SbrEnv4): operating cost only.
+// batch_type 1 = reaction interval: aeration energy of Kla[-1]; 2 = end of cycle: sum(Kla) of the whole list, pumping of
+// the wastage and the effluent, -246 when the effluent ammonia is not below 4 g/m3.  (Branch 0, a fill interval, adds
+// 0.004*Qin of pumping; the SBROS-v1 plant fills inside reset(), so no call pays it.)
+SBR_DEV double sbr_reward_oci(const SbrPar& p, int batch_type, double kla_last, double kla_sum, double qw, double snh_eff) {
+    const double td = 0.002 / 24;
+    double pe = 0.0, ae_dt = 1.32 * kla_last * td, r_snh = 0.0;
+    if (batch_type == 2) {
+        pe = (0.05 * qw + 0.004 * p.Qeff);
+        ae_dt = 1.32 * kla_sum * td;
+        r_snh = snh_eff < 4 ? 0.0 : -246.0;
+    }
+    const double ae = p.So_sat / (1.8 * 1000) * ae_dt;
+    const double oci = ae + pe;
+    return (0.5 - oci) + r_snh;
+}
+
 SBR_DEV double sbr_clip1(double v) { return v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v); }
 
 // obs_DO ++ obs_EC :1027-1114 (normalisers :150-156, xdot scales :1069-1076) and state = [t, x] / x_1_state
@@ -477,17 +494,32 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
 
 // What is left of SbrOS.step (:1011-1273) after the intervals: reward, done test, terminal phases.  Returns the reward;
 // xa6 is updated to the pre-settle values when the terminal phases run; qw is written only then.
+// OCI = the operating-cost reward (cfg.reward_kind 2) with its running sum(Kla) of the episode's list, ksum: a
+// compile-time variant, so that the default kernels carry none of it.
+template <bool OCI>
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX],
-                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw) {
+                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum) {
     sbr_hist_apply(c, hist);
-    const double r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x);     // wave-uniform choice
+    double r;
+    if (OCI) {
+        ksum = ksum + c.knew[0];
+        if (c.n_new > 1) ksum = ksum + c.knew[1];
+        r = sbr_reward_oci(p, 1, c.kla_last, 0.0, 0.0, 0.0);
+    } else {
+        r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x);     // wave-uniform choice
+    }
     t_obs = c.t;
     dn = false;
     if (c.t >= p.T5_end) {                                               // :1122
         dn = true;
         if (p.terminal) {
             sbr_take6(x, xa6);
+            const double snh_eff = x[10];            // solubles pass the settler unchanged: eff_component[3] (:2642)
             qw = sbr_terminal(p, c, hist, x);
+            if (OCI) {
+                ksum = ksum + c.kla_last;            // Sim_idle's Kla.append (:2578)
+                r = sbr_reward_oci(p, 2, c.kla_last, ksum, qw, snh_eff);
+            }
             t_obs = p.t_cycle;
         }
     }

@@ -34,11 +34,12 @@ class _Box:
 class SbrOS:
     metadata = {"render.modes": ["human"]}                      # :101
 
-    def __init__(self, device=0, seed=None):
+    def __init__(self, device=0, seed=None, reward=None):
         # the reference declares stale spaces (:106-113); these are the real ones of step()
         self.action_space = _Box([0.0, 0.0], [8.0, 15.0])
         self.observation_space = _Box(np.full(18, -np.inf), np.full(18, np.inf))
-        self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64)
+        # reward: None / "eqi_oci" = the reference's (module_reward_EQIOCI.py); "g2anet", "oci" = the other reward modules
+        self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64, reward=reward)
         self._seed = seed
         self._episodes = 0
         self._rewards, self._states = [], []

@@ -36,7 +36,7 @@ class SbrOSVec:
     """
 
     def __init__(self, num_envs, device=0, first_env_id=0, out_dtype=torch.float32, config=None, tables=None,
-                 action_dtype=torch.float32):
+                 action_dtype=torch.float32, reward=None):
         if not torch.cuda.is_available():
             raise _capi.SbrError("SbrOSVec needs a HIP device (torch.cuda.is_available() is False); "
                                  "this package has no CPU fallback")
@@ -45,6 +45,10 @@ class SbrOSVec:
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
         self.first_env_id = int(first_env_id)
         self.cfg = config if config is not None else _capi.default_config()
+        if reward is not None:                # "eqi_oci" (the reference's SBROS-v1 reward) | "g2anet" | "oci"
+            if reward not in _capi.REWARD_KINDS:
+                raise ValueError("reward must be one of %s" % sorted(_capi.REWARD_KINDS))
+            self.cfg.reward_kind = _capi.REWARD_KINDS[reward]
         if out_dtype not in (torch.float32, torch.float64):
             raise ValueError("out_dtype must be torch.float32 or torch.float64")
         self.out_dtype = out_dtype

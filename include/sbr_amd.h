@@ -40,7 +40,7 @@ extern "C" {
 #define SBR_KLA_HIST 10    /* Kla values the reward can look back on (current + 9) */
 /* controller/bookkeeping doubles per env exposed by sbr_get_state/sbr_set_state, in this order.  This is the PUBLIC
  * layout; the kernels keep a leaner internal one (Kla history as a ring, packed bookkeeping) and translate. */
-#define SBR_NCTRL 23
+#define SBR_NCTRL 24
 enum {
     SBR_C_T = 0,           /* running time t (days)                     gym_SBR_oneshot.py:1357 */
     SBR_C_SO_M1, SBR_C_SO_M2, SBR_C_SNO_M1, SBR_C_SNO_M2,   /* So[-1] So[-2] Sno[-1] Sno[-2]  :1959-1961 */
@@ -52,7 +52,10 @@ enum {
     SBR_C_RETURN,                                           /* sum of rewards since reset */
     SBR_C_STEPS,                                            /* step() calls since reset (as double) */
     SBR_C_DONE,                                             /* 1.0 once the episode ended */
-    SBR_C_STATUS                                            /* sticky SBR_ST_* bits since reset (as double) */
+    SBR_C_STATUS,                                           /* sticky SBR_ST_* bits since reset (as double) */
+    SBR_C_KLA_SUM                                           /* sum(Kla) of the episode's whole list, in append order:
+                                                               the 252 reset entries (:323), one per interval, idle's.
+                                                               Advanced only with reward_kind 2 (else: its reset value) */
 };
 /* (The reference's u_DO / u_EC globals and the EC value before EC[-1] are temporaries of one step() call - every
  * interval overwrites them before use - so they are not part of the state.) */
@@ -101,7 +104,11 @@ typedef struct sbr_config {
     int32_t out_f64;           /* 0: obs/state/reward are float32; 1: float64 */
     int32_t terminal;          /* 1: run settle/draw/idle on the done step (reference behaviour) */
     int32_t reward_kind;       /* 0: EQI/OCI reward of module_reward_EQIOCI.py (SBROS-v1); 1: the piecewise-linear reward of
-                                  module_reward_continuous_G2ANET.py:4-45 (used by the variant gym_SBR_oneshot_copy.py:17,614) */
+                                  module_reward_continuous_G2ANET.py:4-45 (used by the variant gym_SBR_oneshot_copy.py:17,614);
+                                  2: the operating-cost reward of module_reward_continuous.py:4-65 (SbrEnv3/SbrEnv4): its
+                                  reaction-interval branch (0.5 - AE of the Kla just applied) on every call, and on the
+                                  done call, when the terminal phases run, its end-of-cycle branch (sum(Kla) of the whole
+                                  episode, pumping of Qw and Qeff, -246 if the effluent ammonia is >= 4 g/m3) */
     int32_t act_f64;           /* 0: sbr_step reads float32 actions; 1: float64.  A finished env ignores step()
                                   until sbr_reset either way (the reference leaves resetting to the caller) */
 } sbr_config;

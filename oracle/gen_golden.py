@@ -433,6 +433,30 @@ def run_cycle_env(actions, seed):
     return rec
 
 
+def reward_oci_kats(seed=5, n=120):
+    """Known answers of module_reward_continuous.py:4-65 (the reward of SbrEnv3/SbrEnv4, whose step() does not run under
+    this numpy; the reward is a pure function): random Kla lists of ragged length, every batch_type branch, ammonia
+    either side of the 4 g/m3 penalty threshold.  The list is stored as its last value, its left-to-right sum and its
+    length - what a running implementation keeps."""
+    from gym_SBR.envs.module_reward_continuous import sbr_reward as oci
+    rs = np.random.RandomState(seed)
+    rec = {k: [] for k in ("so_sat", "kla_last", "kla_sum", "kla_len", "batch_type", "qin", "qw", "q_eff", "snh_eff",
+                           "reward")}
+    so_sat = 8.000000000006622                                  # DO_set(15), what gym_SBR_env4.py:357 passes
+    for i in range(n):
+        kla = rs.uniform(0, 240, rs.randint(1, 800)).tolist()
+        if i % 7 == 0:
+            kla = [0] + kla                                     # the lists start with an integer 0 (gym_SBR_env4.py:277)
+        bt = i % 3
+        qin, qw, q_eff = rs.uniform(0.5, 0.8), rs.uniform(0, 0.1), rs.uniform(0.5, 0.8)
+        snh = [3.999, 4.0, 0.1, 25.0][i % 4] if i < 16 else rs.uniform(0, 8)
+        eff = [q_eff, 10.0, 50.0, snh, 5.0, 8.0, qw]
+        r = oci(so_sat, kla, bt, qin, qw, eff if bt == 2 else [])
+        for k, v in zip(rec, (so_sat, kla[-1], sum(kla), len(kla), bt, qin, qw, q_eff, snh, r)):
+            rec[k].append(v)
+    return {k: np.asarray(v, dtype=np.int64 if k in ("kla_len", "batch_type") else np.float64) for k, v in rec.items()}
+
+
 def phase_constants(M):
     return dict(T1_end=np.float64(M.t_memory1[-1]), T3_0=np.float64(M.t_memory3[0]),
                 T3_end=np.float64(M.t_memory3[-1]), T4_end=np.float64(M.t_memory4[-1]),
@@ -450,10 +474,14 @@ def phase_constants(M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="regenerate one fixture only: reward_oci")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     M = import_reference()
+    np.savez_compressed(os.path.join(out, "reward_oci_kat.npz"), **reward_oci_kats())
+    if args.only == "reward_oci":
+        return
 
     np.savez_compressed(os.path.join(out, "constants.npz"), **phase_constants(M))
     means, stds = capture_influent_tables()

@@ -46,6 +46,7 @@ typedef struct {
     double u_do, u_ec;
     double kla_hist[KLA_HIST];      /* oldest first; [KLA_HIST-1] is the current interval's Kla */
     double qw, ret, steps, done, status;
+    double kla_sum;                 /* sum(Kla) over the episode's whole list, in append order (reward_kind 2) */
     double influent[NX];            /* loading vector, [0] = Qin/T_fill */
     double x_start[NX];             /* start state of the last interval (for xdot) */
     double span;                    /* t_range[-1]-t_range[0] of the last interval */
@@ -299,6 +300,8 @@ static void reset_from(const sbro_params* p, sbro_env* e, const double* influent
     /* Kla list = [0, kla] replicated (:323): the tail alternates, newest = kla */
     for (int j = 0; j < KLA_HIST; ++j) e->kla_hist[j] = ((KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;
     e->kla_last = kla; e->ec_last = 0; e->ec_prev = 0;
+    e->kla_sum = 0;                                      /* python sum() over [0, kla]*126 (:323), left to right */
+    for (int j = 0; j < n_rows / 2; ++j) { e->kla_sum = e->kla_sum + 0.0; e->kla_sum = e->kla_sum + kla; }
     e->qw = 0; e->ret = 0; e->steps = 0; e->done = 0;
     e->status = status_bits(p, e->x, 0);
     memcpy(e->x_start, x0c, sizeof x0c);
@@ -349,6 +352,7 @@ static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
     rk4_span(p, 0, e->x, t1 - t0, p->substeps, kla, ec, 0);
     for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];
     e->kla_hist[KLA_HIST - 1] = kla;
+    e->kla_sum = e->kla_sum + kla;
     e->ec_prev = e->ec_last; e->ec_last = ec; e->kla_last = kla;
     e->so_m2 = e->so_m1; e->so_m1 = e->x[8];
     e->sno_m2 = e->sno_m1; e->sno_m1 = e->x[9];
@@ -366,10 +370,31 @@ double sbro_reward_g2anet(const double* x) {
     return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) / 10;
 }
 
+/* module_reward_continuous.py:4-65 (the reward of SbrEnv3/SbrEnv4): operating cost only.  batch_type 0 = fill interval,
+ * 1 = reaction interval (Kla[-1] of the list), 2 = end of cycle (sum(Kla) of the whole list, pumping, ammonia penalty).
+ * The caller passes Kla[-1] and sum(Kla) instead of the list. */
+double sbro_reward_oci(double so_sat, double kla_last, double kla_sum, int32_t batch_type, double qin, double qw,
+                       double q_eff, double snh_eff) {
+    const double t_delta = 0.002 / 24;
+    double pe = 0, ae_dt = 0, r_snh = 0;
+    if (batch_type == 0) { pe = 0.004 * qin; ae_dt = 1.32 * kla_last * t_delta; }
+    if (batch_type == 1) { ae_dt = 1.32 * kla_last * t_delta; pe = 0; }
+    if (batch_type == 2) {
+        pe = (0.05 * qw + 0.004 * q_eff);
+        ae_dt = 1.32 * kla_sum * t_delta;
+        r_snh = snh_eff < 4 ? 0 : -246;
+    }
+    const double ae = so_sat / (1.8 * 1000) * (ae_dt);
+    const double oci = ae + pe;
+    const double r_oci = 0.5 - oci;
+    return r_oci + r_snh;
+}
+
 /* module_reward_EQIOCI.py:4-115 */
 static double reward_of(const sbro_params* p, const sbro_env* e) {
     const double* x = e->x;
     if (p->reward_kind == 1) return sbro_reward_g2anet(x);
+    if (p->reward_kind == 2) return sbro_reward_oci(p->So_sat, e->kla_last, 0, 1, 0, 0, 0, 0);      /* reaction interval */
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
     const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
     const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
@@ -440,6 +465,7 @@ static void terminal(const sbro_params* p, sbro_env* e) {
     rk4_span(p, 2, x, p->t_cycle - t_after_draw, n_rows, kla, 0, 0);
     for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];   /* Kla.append, :2578 */
     e->kla_hist[KLA_HIST - 1] = kla;
+    e->kla_sum = e->kla_sum + kla;
     e->kla_last = kla;
 }
 
@@ -463,16 +489,21 @@ void sbro_step(const sbro_params* p, sbro_env* e, const double* action, double* 
     if (e->t >= p->T3_0 && e->t <= p->T3_end) { e->u_do = a0; e->u_ec = 0; interval(p, e, 1); }
     if (e->t > p->T3_end && e->t <= p->T4_end) { e->u_ec = a1; e->u_do = 0; interval(p, e, 0); }
     if (e->t > p->T4_end) { e->u_do = a0; e->u_ec = 0; interval(p, e, 1); }
-    const double r = reward_of(p, e);
-    e->ret += r; e->steps += 1;
+    double r = reward_of(p, e);
     double t_obs = e->t;
     double xa[NX];
     memcpy(xa, e->x_start, sizeof xa);
     uint8_t dn = 0;
     if (e->t >= p->T5_end) {                              /* :1122 */
         dn = 1; e->done = 1;
-        if (p->terminal) { memcpy(xa, e->x, sizeof xa); terminal(p, e); t_obs = p->t_cycle; }
+        if (p->terminal) {
+            memcpy(xa, e->x, sizeof xa); terminal(p, e); t_obs = p->t_cycle;
+            /* reward_kind 2: the cycle's last reward is the end-of-cycle branch, which needs Qw, the effluent
+             * (eff_component[0] = Qeff, [3] = Snh of the drawn water = the pre-settle Snh) and sum(Kla) incl. idle */
+            if (p->reward_kind == 2) r = sbro_reward_oci(p->So_sat, e->kla_last, e->kla_sum, 2, 0, e->qw, p->Qeff, xa[10]);
+        }
     }
+    e->ret += r; e->steps += 1;
     if (obs) build_obs(t_obs, e->x, xa, e->x, obs);
     if (state) build_state(t_obs, e->x, state);
     if (reward) *reward = r;

@@ -33,14 +33,15 @@ class Env(C.Structure):
                 ("u_do", C.c_double), ("u_ec", C.c_double),
                 ("kla_hist", C.c_double * KLA_HIST),
                 ("qw", C.c_double), ("ret", C.c_double), ("steps", C.c_double), ("done", C.c_double),
-                ("status", C.c_double), ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
+                ("status", C.c_double), ("kla_sum", C.c_double), ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
                 ("n_rows", C.c_int32), ("n_intervals", C.c_int32)]
 
 
 ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "f8"), ("sno_m1", "f8"),
                       ("sno_m2", "f8"), ("ie_do", "f8"), ("ie_ec", "f8"), ("kla_last", "f8"), ("ec_last", "f8"),
                       ("ec_prev", "f8"), ("u_do", "f8"), ("u_ec", "f8"), ("kla_hist", "f8", KLA_HIST),
-                      ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("status", "f8"), ("influent", "f8", NX),
+                      ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("status", "f8"), ("kla_sum", "f8"),
+                      ("influent", "f8", NX),
                       ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4")], align=True)
 
 
@@ -115,7 +116,7 @@ class OracleBatch:
         return out
 
     def load_state(self, x, ctrl):
-        """Overwrite the plant/controller state from the product's PUBLIC layout: x [14][n], ctrl [23][n]
+        """Overwrite the plant/controller state from the product's PUBLIC layout: x [14][n], ctrl [24][n]
         (rows as in include/sbr_amd.h).  Used to re-synchronise the oracle to the device before a call.  The set-points
         in force and the EC before EC[-1] are temporaries of one call (every interval overwrites them first)."""
         x, ctrl = np.asarray(x, dtype=np.float64), np.asarray(ctrl, dtype=np.float64)
@@ -127,6 +128,7 @@ class OracleBatch:
         e["kla_hist"] = ctrl[8:18].T
         e["kla_last"] = ctrl[17]
         e["qw"], e["ret"], e["steps"], e["done"], e["status"] = ctrl[18], ctrl[19], ctrl[20], ctrl[21], ctrl[22]
+        e["kla_sum"] = ctrl[23]
 
     def reset(self, influent):
         influent = np.ascontiguousarray(np.broadcast_to(influent, (self.n, NX)), dtype=np.float64)

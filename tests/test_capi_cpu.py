@@ -35,7 +35,7 @@ def test_header_constants_match_the_binding():
     assert (defs["SBR_NX"], defs["SBR_NOBS"], defs["SBR_NSTATE"], defs["SBR_NCTRL"], defs["SBR_KLA_HIST"]) == (
         _capi.NX, _capi.NOBS, _capi.NSTATE, _capi.NCTRL, _capi.KLA_HIST)
     assert (defs["SBR_ST_NEGATIVE"], defs["SBR_ST_NEAR_POLE"], defs["SBR_ST_NONFINITE"]) == (1, 2, 4)
-    assert _capi.C_STATUS == _capi.NCTRL - 1 == 22 and _capi.C_KLA_LAST == _capi.C_KLA_HIST0 + 9 == 17
+    assert _capi.C_STATUS == 22 and _capi.C_KLA_SUM == _capi.NCTRL - 1 == 23 and _capi.C_KLA_LAST == _capi.C_KLA_HIST0 + 9 == 17
     enum_names = re.findall(r"SBR_C_[A-Z_0-9]+", text.split("enum {")[1].split("};")[0])
     assert enum_names[:8] == ["SBR_C_T", "SBR_C_SO_M1", "SBR_C_SO_M2", "SBR_C_SNO_M1", "SBR_C_SNO_M2", "SBR_C_IE_DO", "SBR_C_IE_EC",
                               "SBR_C_EC_LAST"]

@@ -403,6 +403,56 @@ def test_g2anet_reward_option(G, tables):
     env.close()
 
 
+def test_oci_reward_option(G, tables):
+    """cfg.reward_kind = 2: the operating-cost reward of module_reward_continuous.py:4-65 on the SBROS-v1
+    plant.  Whole episodes against the oracle (whose reward function is pinned bit-exactly by the reference's own, see
+    tests/test_oracle_golden.py): the per-call reward, the running sum(Kla) row, the end-of-cycle reward of the done call
+    (sum over 252 + 466 + 1 list entries, pumping of Qw and Qeff, ammonia penalty), step path and fused rollout."""
+    from gym_sbr2_amd import _capi
+    cfg = _capi.default_config(); cfg.reward_kind = 2; cfg.act_f64 = 1
+    n = 192
+    env = G.SbrOSVec(n, out_dtype=torch.float64, config=cfg)
+    p = O.default_params(); p.reward_kind = 2
+    ora = O.OracleBatch(n, params=p)
+    means, stds = tables
+    z = np.random.RandomState(2).randn(n, 48); scen = (np.arange(n) % 8).astype(np.int32)
+    env.reset(scenario=scen, rnd=z); ora.reset(ora.mix(means, stds, scen, z))
+    assert np.array_equal(_np(env.ctrl_row(_capi.C_KLA_SUM)), ora.envs["kla_sum"])          # 126 * k_fill, summed in order
+    a = np.column_stack([np.linspace(0.5, 4.0, n), np.linspace(0.0, 12.0, n)])          # a spread of set-points
+    at = torch.from_numpy(a).cuda()
+    for c in range(463):
+        _, _, r, d = env.step(at); _, _, orr, od = ora.step(a)
+        assert np.array_equal(_np(d), od)
+        if c < 462:
+            assert np.abs(_np(r) - orr).max() < 1e-10, c
+    assert od.all()
+    # The done call's reward is a function of Qw and sum(Kla), both products of 463 free-running closed-loop calls.  With
+    # their differences removed the two rewards agree to rounding on EVERY env (measured 1.9e-14), i.e. the formula is the
+    # same; the differences themselves are bounded on the envs that stayed away from a Monod pole (measured there:
+    # sum(Kla) 2.6e-8 relative, Qw 1.4e-10, reward 5e-10; 134 of these 192 set-point pairs do reach a pole, see DESIGN.md).
+    ks, oks = _np(env.ctrl_row(_capi.C_KLA_SUM)), ora.envs["kla_sum"]
+    dqw = _np(env.ctrl_row(_capi.C_QW)) - ora.envs["qw"]
+    coef = 8.000000000006622 / 1800 * 1.32 * (0.002 / 24)
+    assert np.abs((_np(r) - orr) + 0.05 * dqw + coef * (ks - oks)).max() < 1e-12
+    clean = ((_np(env.status()) | ora.envs["status"].astype(int)) & _capi.ST_NEAR_POLE) == 0
+    assert clean.sum() >= 40 and oks.min() > 1000.0
+    assert np.abs(ks / oks - 1)[clean].max() < 1e-6 and np.abs(dqw)[clean].max() < 1e-8
+    assert np.abs(_np(r) - orr)[clean].max() < 1e-8
+    rr = _np(r)
+    assert (rr < -200).any() and (rr > 0).any()            # both sides of the ammonia penalty occur in this batch
+    x, ctrl = env.get_state()
+    want = 0.5 - (8.000000000006622 / 1800 * (1.32 * ks * (0.002 / 24)) + 0.05 * _np(ctrl)[_capi.C_QW] + 0.004 * 0.66)
+    assert np.abs(np.where(rr < -200, rr + 246, rr) - want).max() < 1e-12
+    # the row survives a get/set round trip, and the fused rollout keeps it too
+    env.reset(scenario=scen, rnd=z); ora.reset(ora.mix(means, stds, scen, z))
+    ret = env.rollout(463, 9); oret = ora.rollout(463, 9)
+    ok = np.isfinite(oret) & (((_np(env.status()) | ora.envs["status"].astype(int)) & _capi.ST_NEAR_POLE) == 0)
+    assert ok.sum() >= 20 and np.abs(_np(ret)[ok] - oret[ok]).max() < 1e-7      # return ~ 231: 4e-10 relative
+    x, ctrl = env.get_state(); env.set_state(x, ctrl)
+    assert np.array_equal(_np(env.ctrl_row(_capi.C_KLA_SUM)), _np(ctrl)[_capi.C_KLA_SUM])
+    env.close()
+
+
 def test_step_is_hip_graph_capturable(G):
     """sbr_step neither allocates nor synchronises, so a sequence of steps can be captured in a HIP graph and replayed;
     the replayed plant must be bit-identical to stepping eagerly."""

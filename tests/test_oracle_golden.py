@@ -346,3 +346,47 @@ def test_g2anet_reward_known_answers():
     got = np.array([fn(O._p(np.ascontiguousarray(x))) for x in k["X"]])
     assert np.array_equal(got, k["reward"])
     assert len(set(np.round(k["reward"], 6))) > 40
+
+
+def test_oci_reward_known_answers():
+    """cfg.reward_kind = 2: module_reward_continuous.py:4-65 (reward of SbrEnv3/SbrEnv4), values from the reference
+    function itself on 120 ragged Kla lists: all three batch_type branches, ammonia either side of the 4 g/m3 penalty."""
+    import ctypes as C
+    k = golden("reward_oci_kat")
+    fn = O.lib().sbro_reward_oci
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
+    got = np.array([fn(k["so_sat"][i], k["kla_last"][i], k["kla_sum"][i], int(k["batch_type"][i]), k["qin"][i],
+                       k["qw"][i], k["q_eff"][i], k["snh_eff"][i]) for i in range(len(k["reward"]))])
+    assert np.array_equal(got, k["reward"])
+    assert set(k["batch_type"].tolist()) == {0, 1, 2} and (k["reward"] < -200).sum() >= 5      # penalty branch taken
+
+
+def test_oci_reward_episode_bookkeeping():
+    """reward_kind = 2 inside the SBROS-v1 plant: every ordinary call pays the reaction-interval branch on the Kla it
+    applied; the done call pays the end-of-cycle branch on sum(Kla) of the episode's whole list - the 252 reset entries
+    [0, k_fill]*126 (gym_SBR_oneshot.py:323), one Kla per interval (466) and the idle phase's.  The list is rebuilt
+    here from the Kla history after every call and summed with python's own sum()."""
+    infl = golden("sbros_const_2_5")["influent_mixed"]
+    p = O.default_params(); p.reward_kind = 2
+    b = O.OracleBatch(1, p)
+    q = O.default_params(); q.terminal = 0                   # same plant (the reward does not feed back), stops before settling
+    c = O.OracleBatch(1, q)
+    b.reset(infl); c.reset(infl)
+    so_sat, td = 8.000000000006622, 0.002 / 24
+    klas = [0, float(b.envs["kla_last"][0])] * 126
+    a = np.array([[2.0, 5.0]])
+    for call in range(463):
+        _, _, r, d = b.step(a)
+        c.step(a)
+        n_iv = int(c.envs["n_intervals"][0])
+        klas += c.envs["kla_hist"][0][-n_iv:].tolist()
+        if not d[0]:
+            assert r[0] == 0.5 - so_sat / (1.8 * 1000) * (1.32 * klas[-1] * td)
+            assert b.envs["kla_sum"][0] == sum(klas)
+    assert d[0] and len(klas) == 252 + 466
+    klas.append(float(b.envs["kla_hist"][0][-1]))            # Sim_idle's append (:2578)
+    assert b.envs["kla_sum"][0] == sum(klas)
+    qw, snh = float(b.envs["qw"][0]), float(c.envs["x"][0][10])
+    want = 0.5 - (so_sat / (1.8 * 1000) * (1.32 * sum(klas) * td) + (0.05 * qw + 0.004 * 0.66)) + (0 if snh < 4 else -246)
+    assert r[0] == want and 0.0 < want < 0.5 and sum(klas) > 1000.0
