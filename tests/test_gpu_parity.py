@@ -588,6 +588,43 @@ def test_size_independent_properties_at_65536(G):
     env.close(); small.close()
 
 
+def test_indexing_at_134_million_envs(G):
+    """Maximum sizes: 2**27 envs in ONE handle (51 GB of plant/controller/influent rows; element indices into the ctrl
+    block pass 2**31 from row 16 on, obs offsets pass 2**31 at env 119 M).  Envs are independent and keyed by their global
+    id, so three 256-env windows (start, middle, end) must be bit-identical to small handles created with the same
+    first_env_id and fed the same actions."""
+    from gym_sbr2_amd import _capi
+    n, w, calls = 1 << 27, 256, 12
+    big = G.SbrOSVec(n, out_dtype=torch.float64)
+    scen = (torch.arange(n, device="cuda") % 8).to(torch.int32)
+    big.reset(seed=11, scenario=scen)
+    bases = [0, (1 << 26) - 128, n - w]
+    smalls = []
+    for b0 in bases:
+        e = G.SbrOSVec(w, first_env_id=b0, out_dtype=torch.float64)
+        e.reset(seed=11, scenario=scen[b0:b0 + w].contiguous())
+        smalls.append(e)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    for c in range(calls):
+        a = torch.rand(n, 2, device="cuda", generator=gen) * torch.tensor([8.0, 15.0], device="cuda")
+        o, s, r, d = big.step(a)
+        for b0, e in zip(bases, smalls):
+            so, ss, sr, sd = e.step(a[b0:b0 + w].contiguous())
+            assert torch.equal(o[b0:b0 + w], so) and torch.equal(s[b0:b0 + w], ss), (c, b0)
+            assert torch.equal(r[b0:b0 + w], sr) and torch.equal(d[b0:b0 + w], sd), (c, b0)
+    for row in (_capi.C_T, _capi.C_KLA_LAST, _capi.C_KLA_HIST0, _capi.C_RETURN, _capi.C_STEPS, _capi.C_QW):
+        full = big.ctrl_row(row)
+        for b0, e in zip(bases, smalls):
+            assert torch.equal(full[b0:b0 + w], e.ctrl_row(row)), (row, b0)
+    assert bool((big.ctrl_row(_capi.C_STEPS) == calls).all()) and bool(torch.isfinite(r).all())
+    ret = big.episode_returns()
+    st = big.stats(ret)                                            # device reduction over all 2**27 values
+    assert st["count"] == n and st["min"] == float(ret.min().item()) and st["max"] == float(ret.max().item())
+    big.close()
+    for e in smalls:
+        e.close()
+
+
 def test_trajectory_export_matches_reference_per_call(G, tables):
     """sbr_set_trace: one record per call for the traced envs.  Compared with what the reference logged per call in the
     six golden episodes (float64 actions), and with the oracle for the traced subset of a bigger batch."""
