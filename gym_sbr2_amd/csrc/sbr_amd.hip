@@ -532,6 +532,22 @@ static int fail(sbr_env* e, int code, const std::string& msg) {
             return fail(e, SBR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));           \
     } while (0)
 
+// Entry points run on the handle's device and leave the caller's current device as they found it (a process may drive
+// several GPUs, and torch tracks the current device itself).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        int cur = -1;
+        status = hipGetDevice(&cur);
+        if (status == hipSuccess && cur != device) { status = hipSetDevice(device); prev = cur; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(e)                      \
+    DeviceGuard _guard((e)->device);      \
+    HIP_TRY(e, _guard.status)
+
 static void derive_params(const sbr_config& c, SbrPar& p) {
     p.muH = c.muH; p.Ks = c.Ks; p.Koh = c.Koh; p.Kno = c.Kno; p.bH = c.bH; p.eta_g = c.eta_g; p.eta_h = c.eta_h;
     p.kh = c.kh; p.Kx = c.Kx; p.muA = c.muA; p.Knh = c.Knh; p.bA = c.bA; p.Koa = c.Koa; p.ka = c.ka;
@@ -656,7 +672,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
             return fail(nullptr, _s == hipErrorOutOfMemory ? SBR_ERR_ALLOC : SBR_ERR_HIP, m);    \
         }                                                                                        \
     } while (0)
-    CREATE_TRY(hipSetDevice(device_id));
+    DeviceGuard guard(device_id);
+    CREATE_TRY(guard.status);
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, device_id));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
@@ -696,7 +713,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
 
 int sbr_destroy(sbr_env* e) {
     if (!e) return SBR_OK;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     if (e->buf.x) (void)hipFree(e->buf.x);
     if (e->buf.ctrl) (void)hipFree(e->buf.ctrl);
     if (e->buf.infl) (void)hipFree(e->buf.infl);
@@ -712,7 +729,7 @@ int64_t sbr_num_envs(const sbr_env* e) { return e ? e->n : 0; }
 
 int sbr_set_influent_tables(sbr_env* e, const double* means, const double* stds) {
     if (!e || !means || !stds) return fail(e, SBR_ERR_INVALID, "sbr_set_influent_tables: NULL argument");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipMemcpy(e->tables, means, kTableDoubles * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->tables + kTableDoubles, stds, kTableDoubles * sizeof(double), hipMemcpyHostToDevice));
     e->have_tables = true;
@@ -726,7 +743,7 @@ static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scen
     if (!e) return SBR_ERR_INVALID;
     if (!influent && !e->have_tables)
         return fail(e, SBR_ERR_INVALID, "sbr_reset: no influent given and sbr_set_influent_tables was never called");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
     const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
@@ -758,7 +775,7 @@ int sbr_set_trace(sbr_env* e, double* buf, int64_t n_envs, int64_t capacity) {
 
 int sbr_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done, void* stream) {
     if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_step: NULL env or action");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     if (e->cfg.out_f64) {
         if (e->cfg.act_f64) launch_step<double, double>(e, action, obs, state, reward, done, st);
@@ -776,7 +793,7 @@ int sbr_cycle_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const do
     if (!e) return SBR_ERR_INVALID;
     if (!influent && !e->have_tables)
         return fail(e, SBR_ERR_INVALID, "sbr_cycle_reset: no influent given and sbr_set_influent_tables was never called");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
     const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
@@ -791,7 +808,7 @@ int sbr_cycle_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const do
 
 int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, double* diag, void* stream) {
     if (!e || !action) return fail(e, SBR_ERR_INVALID, "sbr_cycle_step: NULL env or action");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
 #define CSTEP(T, A) hipLaunchKernelGGL((k_cycle<T, A>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
@@ -804,7 +821,7 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
 
 int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
     if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
-    HIP_TRY(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     if (e->cfg.reward_kind == 2)
         hipLaunchKernelGGL(k_rollout<true>, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
                            policy_seed, returns, actions_out);
@@ -817,6 +834,7 @@ int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* retur
 
 int sbr_reduce_stats(sbr_env* e, const double* values, int64_t n, double* out4, void* stream) {
     if (!e || !values || !out4 || n < 0) return fail(e, SBR_ERR_INVALID, "sbr_reduce_stats: bad argument");
+    ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(SBR_BLOCK), 0, st, out4);
     if (n > 0) {
@@ -830,6 +848,7 @@ int sbr_reduce_stats(sbr_env* e, const double* values, int64_t n, double* out4, 
 
 int sbr_get_state(sbr_env* e, double* x, double* ctrl, void* stream) {
     if (!e) return SBR_ERR_INVALID;
+    ON_DEVICE(e);
     const size_t nb = (size_t)e->n * sizeof(double);
     if (x) HIP_TRY(e, hipMemcpyAsync(x, e->buf.x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (ctrl) {
@@ -841,6 +860,7 @@ int sbr_get_state(sbr_env* e, double* x, double* ctrl, void* stream) {
 
 int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream) {
     if (!e) return SBR_ERR_INVALID;
+    ON_DEVICE(e);
     const size_t nb = (size_t)e->n * sizeof(double);
     if (x) HIP_TRY(e, hipMemcpyAsync(e->buf.x, x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (ctrl) {
@@ -852,6 +872,7 @@ int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream)
 
 int sbr_get_ctrl_row(sbr_env* e, int32_t row, double* out, void* stream) {
     if (!e || !out || row < 0 || row >= SBR_NCTRL) return fail(e, SBR_ERR_INVALID, "sbr_get_ctrl_row: bad argument");
+    ON_DEVICE(e);
     if (row == SBR_C_RETURN) {           // stored as is: a plain device-to-device copy
         HIP_TRY(e, hipMemcpyAsync(out, e->buf.ctrl + (size_t)R_RET * e->n, (size_t)e->n * sizeof(double),
                                   hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -864,6 +885,7 @@ int sbr_get_ctrl_row(sbr_env* e, int32_t row, double* out, void* stream) {
 
 int sbr_get_influent(sbr_env* e, double* out, void* stream) {
     if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_get_influent: NULL argument");
+    ON_DEVICE(e);
     HIP_TRY(e, hipMemcpyAsync(out, e->buf.infl, SBR_NX * (size_t)e->n * sizeof(double), hipMemcpyDeviceToDevice,
                               (hipStream_t)stream));
     return SBR_OK;
@@ -873,6 +895,7 @@ int sbr_eval_rhs(sbr_env* e, int32_t kind, int64_t n, const double* x, const dou
                  const double* loading, double* dx, void* stream) {
     if (!e || !x || !kla || !ec || !dx || kind < 0 || kind > 2 || (kind == 1 && !loading))
         return fail(e, SBR_ERR_INVALID, "sbr_eval_rhs: bad argument");
+    ON_DEVICE(e);
     if (n > 0)
         hipLaunchKernelGGL(k_rhs, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, kind, n, x, kla, ec,
                            loading, dx);
@@ -882,6 +905,7 @@ int sbr_eval_rhs(sbr_env* e, int32_t kind, int64_t n, const double* x, const dou
 
 int sbr_draw_normals(sbr_env* e, uint64_t seed, double* out, void* stream) {
     if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_draw_normals: NULL argument");
+    ON_DEVICE(e);
     hipLaunchKernelGGL(k_normals, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->buf, seed, out);
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
@@ -889,12 +913,14 @@ int sbr_draw_normals(sbr_env* e, uint64_t seed, double* out, void* stream) {
 
 int sbr_timer_start(sbr_env* e, void* stream) {
     if (!e) return SBR_ERR_INVALID;
+    ON_DEVICE(e);
     HIP_TRY(e, hipEventRecord(e->ev0, (hipStream_t)stream));
     return SBR_OK;
 }
 
 int sbr_timer_stop(sbr_env* e, void* stream, float* elapsed_ms) {
     if (!e || !elapsed_ms) return SBR_ERR_INVALID;
+    ON_DEVICE(e);
     HIP_TRY(e, hipEventRecord(e->ev1, (hipStream_t)stream));
     HIP_TRY(e, hipEventSynchronize(e->ev1));
     HIP_TRY(e, hipEventElapsedTime(elapsed_ms, e->ev0, e->ev1));
