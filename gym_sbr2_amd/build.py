@@ -1,4 +1,11 @@
-"""Builds libsbr_amd.so (HIP, gfx950 only) in-tree: gym_sbr2_amd/lib/libsbr_amd.so."""
+"""Builds libsbr_amd.so (HIP, gfx950 only) in-tree: gym_sbr2_amd/lib/libsbr_amd.so.
+
+Staleness is decided by CONTENT, not by mtime: the hash of the sources and flags the library was built from is kept next to
+it (libsbr_amd.so.srchash).  A copied tree (e.g. the snapshot sent to a GPU box) has arbitrary mtimes, and eight ranks that
+all thought the library stale would otherwise run hipcc into the same file at once.  The build itself is serialised with a
+file lock and published with an atomic rename, so a concurrent loader sees either the old library or the new one."""
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -8,6 +15,7 @@ SRC = os.path.join(_HERE, "csrc", "sbr_amd.hip")
 DEPS = [SRC, os.path.join(_HERE, "csrc", "sbr_device.h"),
         os.path.join(os.path.dirname(_HERE), "include", "sbr_amd.h")]
 LIB = os.path.join(_HERE, "lib", "libsbr_amd.so")
+HASH = LIB + ".srchash"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math"]
 
 
@@ -18,18 +26,45 @@ def hipcc():
     return exe
 
 
+def source_hash():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(b"\0" + os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def is_stale():
-    return (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    if not os.path.exists(LIB) or not os.path.exists(HASH):
+        return True
+    with open(HASH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():          # another process built it while this one waited
+                return LIB
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc()] + FLAGS + ["-o", tmp, SRC]
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            with open(HASH + ".tmp", "w") as f:
+                f.write(source_hash() + "\n")
+            os.replace(HASH + ".tmp", HASH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -45,10 +45,30 @@ ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "
                       ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4")], align=True)
 
 
+def _src_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("sbr_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "sbr_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsbr_oracle.so"])
+    """Stale = the library was built from other sources (content hash next to it; mtimes do not survive a copied tree).
+    Serialised by a file lock so that several processes can call this at once."""
+    import fcntl
+    tag = _LIB + ".srchash"
+
+    def stale():
+        return not (os.path.exists(_LIB) and os.path.exists(tag) and open(tag).read().strip() == _src_hash())
+    if force or stale():
+        with open(_LIB + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libsbr_oracle.so"])
+                with open(tag, "w") as f:
+                    f.write(_src_hash() + "\n")
     return _LIB
 
 
