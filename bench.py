@@ -247,10 +247,14 @@ def main():
     achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
     # HBM bytes per launch from the PMC counters: collected offline with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
     # passes, gfx950 correction calibrated in the same run) and committed under profiles/; valid for this workload only
-    traffic = None
+    traffic, traffic_note = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not fused and n_local == 65536 and os.path.exists(pmc):
-        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        rec = json.load(open(pmc))
+        traffic = rec["hbm_bytes_per_launch"]
+        traffic_note = ("bytes per launch (profiles/r01_pmc_traffic.json: %.0f B per env-step vs %d algorithmic; the internal "
+                        "layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
+                        % (rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
     out = {
         "metric": "env-steps/sec (batched)",
         "value": n_global * args.steps / elapsed,
@@ -266,10 +270,10 @@ def main():
                                 "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload],
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
                    "resets_in_timed_region": max(state["episode"] - 2, 0), "actions": "uniform random set-points, float32, resident in HBM",
-                   "kernel": "k_rollout" if fused else "k_step<float,float,%d>" % (2 if n_local > 98304 else 1)},
+                   "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (2 if n_local > 98304 else 1)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": "bytes per launch (profiles/r01_pmc_traffic.json: 724 B per env-step vs 513 algorithmic; every byte moves once)",
+                     "traffic_unit": traffic_note,
                      "algorithmic_bytes_per_launch": n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP,
                      "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                      "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,

@@ -1,0 +1,112 @@
+"""Distils gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/:
+    <tag>_bench_<workload>.json, <tag>_bench_config2_kernel_stats.csv, <tag>_pmc_{fetch,write,sq}_by_kernel.csv,
+    <tag>_pmc_traffic.json  (HBM bytes per k_step launch, read by bench.py as roofline.traffic)
+Unit handling as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counter values are KiB; WRITE_SIZE is exact; on gfx950
+FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is corrected with the factor measured IN THE SAME PASS on
+device-to-device copies of known size (scripts/pmc_workload.py).   usage: python scripts/pmc_summarise.py r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+CAL_BYTES = 64 << 20
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[0]
+
+
+def counters(pass_dir):
+    """{counter: {kernel: [values]}} of one PMC pass, plus durations per kernel"""
+    vals = defaultdict(lambda: defaultdict(list))
+    with open(one(pass_dir + "/**/*counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            vals[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return vals
+
+
+def short(k):
+    return k.split("(")[0][:60]
+
+
+def by_kernel_csv(path, name, table):
+    with open(path, "w") as f:
+        f.write("kernel,dispatches,mean_%s,min,max\n" % name)
+        for k, v in sorted(table.items(), key=lambda kv: -sum(kv[1]))[:12]:
+            f.write('"%s",%d,%.1f,%.1f,%.1f\n' % (short(k), len(v), sum(v) / len(v), min(v), max(v)))
+
+
+for w in ("config2", "config1", "config5", "cycle"):
+    p = os.path.join(src, "bench_%s.json" % w)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, "%s_bench_%s.json" % (tag, w)))
+shutil.copy(one("trace_config2/**/*kernel_stats.csv"), os.path.join(dst, "%s_bench_config2_kernel_stats.csv" % tag))
+
+fetch, write = counters("pmc_fetch")["FETCH_SIZE"], counters("pmc_write")["WRITE_SIZE"]
+by_kernel_csv(os.path.join(dst, "%s_pmc_fetch_by_kernel.csv" % tag), "FETCH_SIZE_KiB", fetch)
+by_kernel_csv(os.path.join(dst, "%s_pmc_write_by_kernel.csv" % tag), "WRITE_SIZE_KiB", write)
+
+
+def pick(table, needle):
+    ks = [k for k in table if needle in k]
+    if not ks:
+        raise SystemExit("no kernel matching %r" % needle)
+    return max(ks, key=lambda k: len(table[k]))
+
+
+def mean(v):
+    return sum(v) / len(v)
+
+
+step_k = pick(fetch, "k_step<")
+cal_f = [v for k in fetch if "copyBuffer" in k for v in fetch[k] if v * 1024 > 0.25 * CAL_BYTES]
+cal_w = [v for k in write if "copyBuffer" in k for v in write[k] if v * 1024 > 0.5 * CAL_BYTES]
+if len(cal_f) < 4 or len(cal_w) < 4:
+    raise SystemExit("calibration copies not found in the PMC passes (%d, %d)" % (len(cal_f), len(cal_w)))
+f_factor = mean(cal_f) * 1024 / CAL_BYTES          # ~0.50 on gfx950
+w_factor = mean(cal_w) * 1024 / CAL_BYTES          # ~1.00
+n_envs = 65536
+fetch_raw = mean(fetch[step_k]) * 1024
+fetch_b = fetch_raw / f_factor
+write_b = mean(write[pick(write, "k_step<")]) * 1024 / w_factor
+out = {
+    "source": "scripts/profile_round.sh %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (each with "
+              "--kernel-trace only) over scripts/pmc_workload.py = calibration copies + `bench.py --no-cpu-baseline --steps 463` "
+              "on MI355X; MEANS over the k_step dispatches" % tag,
+    "unit_note": "counter values are KiB.  Both counters are calibrated in their own pass on eight %d-byte device-to-device "
+                 "copies (__amd_rocclr_copyBuffer): WRITE_SIZE/bytes = %.4f, FETCH_SIZE/bytes = %.4f (gfx950 tallies 128-byte "
+                 "fetches at 64 bytes, MI355X_MICROARCH.md HBM section)" % (CAL_BYTES, w_factor, f_factor),
+    "envs_per_launch": n_envs, "kernel": short(step_k), "dispatches": len(fetch[step_k]),
+    "FETCH_SIZE_raw_bytes": fetch_raw, "fetch_calibration_factor": f_factor, "write_calibration_factor": w_factor,
+    "fetch_corrected_bytes": fetch_b, "WRITE_SIZE_bytes": write_b,
+    "hbm_bytes_per_launch": fetch_b + write_b, "hbm_bytes_per_env_step": (fetch_b + write_b) / n_envs,
+    "expected_from_code": {"read_bytes_per_env": 264,
+                           "write_bytes_per_env": "313 when no lane of the wave dosed carbon (V, Si, Xi not stored), 337 otherwise",
+                           "note": "x 112 R; 18 ctrl rows R = 144; action 8 R; x 88-112 W; 11 ctrl rows W = 88; obs 72 + state 60 + "
+                                   "reward 4 + done 1 W"},
+    "algorithmic_bytes_per_env_step": 513,
+}
+json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+print("k_step: fetch %.2f MB + write %.2f MB = %.1f B per env-step (factors %.4f / %.4f)"
+      % (fetch_b / 1e6, write_b / 1e6, out["hbm_bytes_per_env_step"], f_factor, w_factor))
+
+try:
+    sq = counters("pmc_sq")
+    with open(os.path.join(dst, "%s_pmc_sq_by_kernel.csv" % tag), "w") as f:
+        names = sorted(sq)
+        f.write("kernel,dispatches," + ",".join("mean_" + n for n in names) + "\n")
+        kernels = sorted({k for n in names for k in sq[n]}, key=lambda k: -len(sq[names[0]].get(k, [])))[:8]
+        for k in kernels:
+            f.write('"%s",%d,' % (short(k), len(sq[names[0]].get(k, []))) +
+                    ",".join("%.1f" % mean(sq[n][k]) if sq[n].get(k) else "" for n in names) + "\n")
+except SystemExit:
+    print("no SQ pass")

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profiling recipe of a round, to be run ON THE GPU BOX (inside one gpurun call):
+#   gpurun --timeout 900 -- 'bash scripts/profile_round.sh r01'
+# Writes everything under gpurun_out/<tag>/; scripts/pmc_summarise.py then distils it into profiles/.
+# Separate passes on purpose: --kernel-trace --stats for durations; one --pmc pass per counter (FETCH_SIZE, WRITE_SIZE),
+# each only with --kernel-trace; the SQ pass last.  python3 is the program directly after `--`.
+set -e -o pipefail
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+for w in config2 config1 config5 cycle; do
+  timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
+  echo "bench $w: $(cut -c1-160 $out/bench_$w.json)"
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_config2 -o run --output-format csv -- python3 bench.py --no-cpu-baseline > $out/bench_config2_profiled.json 2> $out/rocprof_trace.err
+echo "kernel trace done"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_fetch -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_fetch.json 2> $out/pmc_fetch.err
+echo "FETCH_SIZE pass done"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pmc_write -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_write.json 2> $out/pmc_write.err
+echo "WRITE_SIZE pass done"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace -d $out/pmc_sq -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_sq.json 2> $out/pmc_sq.err || echo "SQ pass failed (optional)"
+echo "profile_round $tag finished"
