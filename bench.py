@@ -255,6 +255,12 @@ def main():
         traffic_note = ("bytes per launch (profiles/r01_pmc_traffic.json: %.0f B per env-step vs %d algorithmic; the internal "
                         "layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
                         % (rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
+    elif fused and n_local == 65536 and os.path.exists(pmc) and "rollout" in json.load(open(pmc)):
+        rec = json.load(open(pmc))["rollout"]
+        traffic = rec["hbm_bytes_per_launch"]
+        traffic_note = ("bytes per launch of %d calls (profiles/r01_pmc_traffic.json: %.1f B per env-step really moved; `achieved` "
+                        "uses the per-step convention of %d B)" % (rec["calls_per_launch"], rec["hbm_bytes_per_env_step"],
+                                                                  ALGO_BYTES_PER_ENV_STEP))
     out = {
         "metric": "env-steps/sec (batched)",
         "value": n_global * args.steps / elapsed,

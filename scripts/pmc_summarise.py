@@ -95,6 +95,17 @@ out = {
                                    "reward 4 + done 1 W"},
     "algorithmic_bytes_per_env_step": 513,
 }
+try:                                     # the fused rollout: one launch = a whole episode of 463 calls kept in registers
+    rk = pick(fetch, "k_rollout<")
+    rf = max(fetch[rk]) * 1024 / f_factor            # the 463-call launches (the warm-up launch is shorter)
+    rw = max(write[pick(write, "k_rollout<")]) * 1024 / w_factor
+    out["rollout"] = {"kernel": short(rk), "dispatches": len(fetch[rk]), "calls_per_launch": 463,
+                      "hbm_bytes_per_launch": rf + rw, "hbm_bytes_per_env_step": (rf + rw) / n_envs / 463,
+                      "note": "plant and controller state are loaded once and stored once per launch; the per-step convention "
+                              "would charge 463 x 513 B per env"}
+    print("k_rollout: %.2f MB per launch = %.2f B per env-step" % ((rf + rw) / 1e6, out["rollout"]["hbm_bytes_per_env_step"]))
+except SystemExit:
+    print("no k_rollout dispatches in the PMC passes")
 json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print("k_step: fetch %.2f MB + write %.2f MB = %.1f B per env-step (factors %.4f / %.4f)"
       % (fetch_b / 1e6, write_b / 1e6, out["hbm_bytes_per_env_step"], f_factor, w_factor))

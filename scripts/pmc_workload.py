@@ -1,5 +1,5 @@
 """Workload for the rocprofv3 PMC passes: device-to-device calibration copies of known size, then the default bench
-workload (config2, one episode).  Run as `rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 scripts/pmc_workload.py`
+workload (config2, one episode) and the fused rollout (config5, one episode).  Run as `rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 scripts/pmc_workload.py`
 (python3 directly after `--`; FETCH_SIZE and WRITE_SIZE in SEPARATE passes)."""
 import os
 import runpy
@@ -17,5 +17,6 @@ for _ in range(8):
     dst.copy_(src)
 torch.cuda.synchronize()
 print("calibration: 8 device-to-device copies of %d bytes" % CAL_BYTES, file=sys.stderr)
-sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "463", "--warmup", "20"]
-runpy.run_path(sys.argv[0], run_name="__main__")
+for workload in ("config2", "config5"):          # per-step kernel, then the fused rollout (one launch = 463 calls)
+    sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "463", "--warmup", "20", "--workload", workload]
+    runpy.run_path(sys.argv[0], run_name="__main__")
