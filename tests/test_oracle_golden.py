@@ -390,3 +390,40 @@ def test_oci_reward_episode_bookkeeping():
     qw, snh = float(b.envs["qw"][0]), float(c.envs["x"][0][10])
     want = 0.5 - (so_sat / (1.8 * 1000) * (1.32 * sum(klas) * td) + (0.05 * qw + 0.004 * 0.66)) + (0 if snh < 4 else -246)
     assert r[0] == want and 0.0 < want < 0.5 and sum(klas) > 1000.0
+
+
+def test_substep_count_is_set_by_accuracy_and_stability():
+    """Why cfg.substeps = 10.  Open loop over ALL golden intervals (2796), C oracle, gate against the reference's
+    own LSODA end state: 8 substeps of classical RK4 miss the 1e-5 gate, 10 meet it with a factor ~2 in hand, and the error
+    falls as h^4 (so it is truncation error, not the reference's).  Stability: h = dt keeps lambda*h of the stiffest mode seen on
+    the golden states near 1, well inside RK4's real stability interval of 2.785."""
+    import ctypes as C
+    lib, p = O.lib(), O.default_params()
+    lib.sbro_rk4.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_double, C.c_double,
+                             C.POINTER(C.c_double)]
+    lib.sbro_rhs_reaction.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double)]
+    worst = {n: 0.0 for n in (6, 8, 10, 20)}
+    count, lam_max = 0, 0.0
+    for name in EPISODES:
+        e = golden("sbros_" + name)
+        for i in range(len(e["iv_kind"])):
+            span = float(e["iv_t_end"][i]) - float(e["iv_t_start"][i])
+            kla, ec = float(e["iv_Kla"][i]), float(e["iv_EC"][i])
+            for n in worst:
+                x = e["iv_x_start"][i].copy()
+                lib.sbro_rk4(C.byref(p), 0, O._p(x), span, n, kla, ec, None)
+                worst[n] = max(worst[n], gate(x, e["iv_x_end"][i]).max())
+            count += 1
+            if i % 8 == 0:          # the stiffest direction is dissolved oxygen: d(dSo/dt)/dSo by central differences
+                x = e["iv_x_start"][i].copy()
+                d = 1e-6
+                xp, xm, fp, fm = x.copy(), x.copy(), np.empty(14), np.empty(14)
+                xp[8] += d; xm[8] -= d
+                lib.sbro_rhs_reaction(C.byref(p), O._p(xp), kla, ec, O._p(fp))
+                lib.sbro_rhs_reaction(C.byref(p), O._p(xm), kla, ec, O._p(fm))
+                lam_max = max(lam_max, abs((fp[8] - fm[8]) / (2 * d)))
+    assert count == 2796
+    assert worst[8] > 1.0 > worst[10] > 0.3              # measured 1.19 and 0.51
+    assert worst[6] > 3.0 and worst[20] < 0.05           # measured 3.43 and 0.033
+    assert 10.0 < worst[10] / worst[20] < 20.0           # ~2**4: fourth-order truncation error
+    assert 1.0e4 < lam_max < 1.5e4 and lam_max * P.DT < 2.785 / 2      # measured 12.5e3 per day: lambda*dt = 1.05
