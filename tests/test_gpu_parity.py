@@ -54,6 +54,23 @@ def test_native_library_is_loaded_and_fails_loudly_on_bad_config(G):
     # an env that was never reset is inert: done = 1, reward 0
     _, _, r, d = env.step(torch.zeros(4, 2))
     assert _np(d).tolist() == [1, 1, 1, 1] and _np(r).tolist() == [0, 0, 0, 0]
+    # nulls at the ABI: every output of sbr_step is optional, the action is not; bad rows are refused with a message
+    env.reset(seed=1)
+    a = torch.full((4, 2), 2.0, device="cuda")
+    assert lib.sbr_step(env._h, a.data_ptr(), None, None, None, None, None) == 0
+    torch.cuda.synchronize()
+    assert _np(env.ctrl_row(_capi.C_STEPS)).tolist() == [1, 1, 1, 1]
+    assert lib.sbr_step(env._h, None, None, None, None, None, None) == -1 and b"action" in lib.sbr_last_error(env._h)
+    out = torch.empty(4, dtype=torch.float64, device="cuda")
+    assert lib.sbr_get_ctrl_row(env._h, _capi.NCTRL, out.data_ptr(), None) == -1
+    assert lib.sbr_get_ctrl_row(env._h, -1, out.data_ptr(), None) == -1
+    assert lib.sbr_rollout(env._h, -3, 0, None, None, None) == -1
+    # scenario ids outside 0..7 are clamped, never used as an index
+    z = np.zeros((4, 48))
+    env.reset(scenario=np.array([-5, 0, 7, 100], dtype=np.int32), rnd=z)
+    got = _np(env.influent())
+    env.reset(scenario=np.array([0, 0, 7, 7], dtype=np.int32), rnd=z)
+    assert np.array_equal(got, _np(env.influent()))
     env.close()
 
 
