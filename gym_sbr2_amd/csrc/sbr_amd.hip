@@ -1,11 +1,13 @@
 // sbr_amd.hip - kernels + C ABI of libsbr_amd.so (gfx950).  See include/sbr_amd.h for the contract.
 //
-// Kernels (all one-lane-per-env over SoA float64 state, 64-thread workgroups = one wavefront, so a
-// launch of N envs is N/64 independent waves that the dispatcher spreads over the 1024 SIMDs):
+// Kernels (all one-lane-per-env over SoA float64 state, 256-thread workgroups = four wavefronts, one per SIMD of a CU, so
+// a launch of N envs is N/64 independent waves that the dispatcher spreads over the 1024 SIMDs):
 //   k_reset    influent mix (tables in LDS) + fill phase (252 RK4 substeps) + controller init + obs
 //   k_step     one SbrOS.step(): phase logic, 2 PIDs, 10 RK4 substeps (x2 at phase boundaries), reward,
 //              obs/state, and the terminal phases on the last call of an episode
 //   k_rollout  n_steps fused step()s with an on-device Philox policy, plant state stays in VGPRs
+//   k_cycle_reset, k_cycle   the per-cycle env SBR-v2: one launch = one whole 12 h cycle (528 control intervals)
+//   k_export, k_import       public <-> internal controller layout
 //   k_stats    wavefront (DPP) reductions of a per-env vector -> {sum,min,max,count}
 //   k_rhs, k_normals  known-answer helpers for the parity tests
 #include <hip/hip_runtime.h>
@@ -250,9 +252,10 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // Two builds of the kernel: W = 1 lets the allocator use the whole register file (fastest single wave: batches of up
 // to one wave per SIMD, N <= 65536) and W = 2 keeps two waves resident per SIMD so that the load/store phases of one
 // overlap the arithmetic of the other (measured on MI355X: -4 % at N = 65536, +7 % at 131072, +18 % at 262144).
-// Values that only have to SURVIVE the integration (Kla history, return/steps/status, the xdot start values: 19
-// doubles per lane) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip
-// through L2/HBM, and the RK4 loop keeps its registers.  Slot j of lane l is at park[j*64 + l] (conflict-free).
+// Values that only have to SURVIVE the integration (nine Kla history values, return, packed steps/status/done, the six
+// xdot start values: 17 doubles per lane, 18 with the operating-cost reward's running sum) are parked in LDS, not in
+// VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and the RK4 loop keeps its registers
+// (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l is at park[j*SBR_BLOCK + l] (conflict-free).
 #define SBR_NPARK (SBR_KLA_HIST - 1 + 2 + SBR_NXD)
 template <typename OutT, typename ActT, int W, bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
