@@ -17,7 +17,9 @@ phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
     cycle              65536 envs per GPU of the per-cycle env SBR-v2: one launch = one whole cycle of 528
                        control intervals; a "step" is then one cycle and `value` is still control intervals per second
 Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase) runs INSIDE the timed region and is
-not counted as steps.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
+not counted as steps.  Before the W warm-up steps the same workload runs untimed for PRIME_SECONDS of wall time: the GPU needs
+~25 ms of sustained work to reach its steady clocks (measured with scripts/probes/clock_ramp.py: 20.95 us per launch in the
+first block, 19.5 us from the fourth on, 21.1 us again after 2 s idle), which a warm-up of a few dozen 20-us steps never gives.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
 """
 import argparse
 import json
@@ -32,6 +34,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
+PRIME_SECONDS = 0.3                    # untimed: brings the GPU to steady clocks before warm-up and timing
 
 
 def cpu_baseline(n_envs=16384, calls=463):
@@ -83,6 +86,10 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
+        one(50)
+        torch.cuda.synchronize(dev)
     for k in range(max(1, min(args.warmup, 3))):
         one(k)
     fence()
@@ -103,6 +110,7 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
            "config": {"workload": "SBR-v2 per-cycle env (SURVEY.md 8f-3): %d envs/GPU, one step = reset + one whole 12 h cycle = %d "
                                   "control intervals of RK4 (10 substeps); value counts control intervals" % (n_local, INTERVALS_PER_CYCLE),
                       "envs_per_gpu": n_local, "envs_total": n_global, "cycles_per_s": n_global * steps / elapsed,
+                      "clock_priming_s": PRIME_SECONDS,
                       "kernel": "k_cycle<float,float> (+ k_cycle_reset)"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": None, "avg_launch_us": per_launch_s * 1e6,
@@ -228,8 +236,13 @@ def main():
     reset()
     end_of_episode()
     reset()
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
+        run(CALLS_PER_EPISODE, record=False)
+        torch.cuda.synchronize(dev)
     run(args.warmup, record=False)
     fence()
+    episodes_before = state["episode"]
     t0 = time.perf_counter()
     run(args.steps, record=True)
     fence()
@@ -239,6 +252,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    resets_timed = state["episode"] - episodes_before
     # dominant kernel: device time of the step launches of the timed region, from events on the launch stream
     dev_ms = sum(a.elapsed_time(b) for a, b, _ in seg_events)
     launches = sum(m for _, _, m in seg_events) if not fused else len(seg_events)
@@ -275,7 +289,7 @@ def main():
                                                              "episode (configs[3] shape)" % world if world > 1 else ""),
                                 "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload],
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
-                   "resets_in_timed_region": max(state["episode"] - 2, 0), "actions": "uniform random set-points, float32, resident in HBM",
+                   "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS, "actions": "uniform random set-points, float32, resident in HBM",
                    "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (2 if n_local > 98304 else 1)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
