@@ -34,6 +34,10 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
+# float64 operations per env-step, counted in the gfx950 ISA of the RK4 loop that runs when no lane of the wave doses carbon
+# (155 FMA x 2 + 172 MUL + 36 ADD + 4 RCP = 522 per substep, x 10 substeps; 682 per substep with dosing): a LOWER bound
+FP64_FLOP_PER_ENV_STEP = 5220
+FP64_VECTOR_PEAK_TFLOPS = 78.6         # /opt/skills/guides/MI355X_MICROARCH.md: vector float64
 PRIME_SECONDS = 0.3                    # untimed: brings the GPU to steady clocks before warm-up and timing
 
 
@@ -300,7 +304,12 @@ def main():
                      "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms,
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
                                          "host_in_reset_issue": acct["reset_issue_ms"]},
-                     "note": "fp64 VALU-bound, not HBM-bound: ~5.7 kFLOP per env-step at ~11 FLOP/B (SURVEY.md 8d); see DESIGN.md"},
+                     "fp64_valu": {"achieved": n_local * calls_per_launch * FP64_FLOP_PER_ENV_STEP / per_launch_s / 1e12,
+                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": n_local * calls_per_launch * FP64_FLOP_PER_ENV_STEP / per_launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                   "flop_per_env_step": FP64_FLOP_PER_ENV_STEP,
+                                   "note": "informative: ISA count of the no-dosing RK4 loop (FMA = 2), a lower bound"},
+                     "note": "fp64 VALU-bound, not HBM-bound: >= 5.2 kFLOP per env-step at ~10 FLOP/B (SURVEY.md 8d); see DESIGN.md"},
         "env_status": {"near_pole_frac_last_episode": float(((status_snap.to(torch.int64) & _capi.ST_NEAR_POLE) != 0).float().mean().item())
                        if state["episode"] > 2 else None,
                        "nonfinite": int(((status_snap.to(torch.int64) & _capi.ST_NONFINITE) != 0).sum().item()),
