@@ -40,6 +40,7 @@ class SbrOS:
         self.observation_space = _Box(np.full(18, -np.inf), np.full(18, np.inf))
         # reward: None / "eqi_oci" = the reference's (module_reward_EQIOCI.py); "g2anet", "oci" = the other reward modules
         self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64, reward=reward)
+        self._vec.enable_host_io()        # the kernel reads the action from, and writes its outputs to, pinned host memory
         self._seed = seed
         self._episodes = 0
         self._rewards, self._states = [], []
@@ -67,13 +68,12 @@ class SbrOS:
         return self._split(obs[0].cpu())
 
     def step(self, action):
-        a = torch.tensor([[float(action[0]), float(action[1])]], dtype=torch.float64)
-        obs, state, reward, done = self._vec.step(a)
-        obs, state = obs[0].cpu(), state[0].cpu().numpy()
-        reward, done = float(reward[0].item()), bool(done[0].item())
+        obs, state, reward, done = self._vec.step_host([[float(action[0]), float(action[1])]])
+        state = state[0].copy()
+        reward, done = float(reward[0]), bool(done[0])
         self._rewards.append(reward)
         self._states.append(state)
-        return self._split(obs), state, reward, done, {}
+        return self._split(obs[0]), state, reward, done, {}
 
     def get_available_actions(self, pre_action, n_agents, n_action):
         """Mask of the discrete set-point moves that stay inside the action bounds (:440-459)."""

@@ -122,6 +122,34 @@ class SbrOSVec:
         self._keep_a = a
         return self.obs, self.state, self.reward, self.done
 
+    def enable_host_io(self):
+        """Small batches driven from the host (the reference-shaped single env): allocate PINNED host buffers for the action
+        and for obs/state/reward/done and let the kernel read and write them directly over PCIe (pinned host memory is
+        device-accessible), so that a step costs one launch and one stream synchronisation instead of one host-to-device
+        and four device-to-host copies.  Returns the numpy views that step_host() fills."""
+        np_out = {torch.float32: np.float32, torch.float64: np.float64}
+        n = self.num_envs
+        self._h_act = torch.empty((n, 2), dtype=self.action_dtype).pin_memory()
+        self._h_obs = torch.empty((n, _capi.NOBS), dtype=self.out_dtype).pin_memory()
+        self._h_state = torch.empty((n, _capi.NSTATE), dtype=self.out_dtype).pin_memory()
+        self._h_reward = torch.empty((n,), dtype=self.out_dtype).pin_memory()
+        self._h_done = torch.empty((n,), dtype=torch.uint8).pin_memory()
+        self._h_views = (self._h_act.numpy(), self._h_obs.numpy(), self._h_state.numpy(), self._h_reward.numpy(),
+                         self._h_done.numpy())
+        return self._h_views
+
+    def step_host(self, action):
+        """step() through the pinned host buffers of enable_host_io(): action is array-like [N,2]; returns numpy views of
+        obs, state, reward, done, valid until the next call (the stream has been synchronised)."""
+        act, obs, state, reward, done = self._h_views
+        act[...] = action
+        st = torch.cuda.current_stream(self.device)
+        _capi.check(self.lib.sbr_step(self._h, C.c_void_p(self._h_act.data_ptr()), C.c_void_p(self._h_obs.data_ptr()),
+                                      C.c_void_p(self._h_state.data_ptr()), C.c_void_p(self._h_reward.data_ptr()),
+                                      C.c_void_p(self._h_done.data_ptr()), C.c_void_p(st.cuda_stream)), self._h)
+        st.synchronize()
+        return obs, state, reward, done
+
     def capture_steps(self, actions):
         """Capture one step() per action tensor of `actions` (a sequence of [N,2] device tensors at fixed addresses) into a
         HIP graph and return it; graph.replay() then issues all of them with one host call (0.4 us per step instead of

@@ -808,6 +808,27 @@ def test_two_processes_sharded_by_global_env_id(G, tmp_path):
     env.close()
 
 
+def test_pinned_host_io_equals_device_io(G):
+    """step_host(): the kernel reads the action from, and writes obs/state/reward/done to, pinned host memory; same numbers
+    as the device-tensor path, bit for bit, over a whole episode including the done call."""
+    n = 5
+    a_env, b_env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64), \
+        G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    views = b_env.enable_host_io()
+    assert views[1].shape == (n, 18) and views[2].shape == (n, 15) and b_env._h_obs.is_pinned()
+    scen = np.arange(n, dtype=np.int32)
+    a_env.reset(seed=3, scenario=scen); b_env.reset(seed=3, scenario=scen)
+    rs = np.random.RandomState(0)
+    for c in range(463):
+        act = np.column_stack([rs.uniform(0, 8, n), rs.uniform(0, 15, n)])
+        o, s, r, d = a_env.step(torch.from_numpy(act))
+        ho, hs, hr, hd = b_env.step_host(act)
+        assert np.array_equal(_np(o), ho) and np.array_equal(_np(s), hs) and np.array_equal(_np(r), hr), c
+        assert np.array_equal(_np(d), hd), c
+    assert hd.all()
+    a_env.close(); b_env.close()
+
+
 def test_reference_shaped_single_env(G):
     """The N = 1 class keeps the reference's surface: reset() -> (list9, list9); step -> 5-tuple (:438, :1273)."""
     e = golden("sbros_const_2_5")
