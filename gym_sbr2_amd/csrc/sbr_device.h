@@ -224,8 +224,8 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double span, int n, d
 
 // ---------------------------------------------------------------------------------------------------
 // Per-env controller registers that are live ACROSS the RK4 loop - kept small on purpose.  The Kla history and
-// the bookkeeping rows (return, steps, status) are not needed until after the integration, so the step kernel
-// loads them afterwards: fewer live VGPRs in the hot loop and the loads overlap nothing worse than before.
+// the bookkeeping rows (return, steps, status) are not needed until after the integration: the step kernel loads them
+// up front with everything else (one exposed round trip) and parks them in LDS, so the hot loop keeps its VGPRs.
 struct SbrCtl {
     double t, so_m1, so_m2, sno_m1, sno_m2, ie_do, ie_ec, ec_last, ec_prev, u_do, u_ec;
     double kla_last;          // Kla[-1]: bias of the velocity-form DO-PID
