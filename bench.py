@@ -30,6 +30,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the platform default; host-resident kernargs cost +4 us per launch
 
 ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -4,8 +4,15 @@ Importing this package never touches the GPU.  `SbrOSVec` / `SbrOS` need a gfx95
 libsbr_amd.so (built in-tree by `__graft_entry__.build()`); there is no CPU fallback.
 (The directory is `gym_sbr2_amd` because `gym-sbr2_amd` is not an importable Python name.)
 """
-from . import _capi  # noqa: F401
-from .registration import make, register_with_gym, registered_ids  # noqa: F401
+import os as _os
+
+# Kernel arguments in device memory: with host-resident kernargs every k_step launch is 4 us slower (measured on MI355X,
+# profiles/r01_notes.md).  It is the HIP runtime's default on this platform; pin it unless the user chose otherwise.  Only
+# effective if set before the HIP runtime initialises, which importing this package early guarantees.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+from . import _capi  # noqa: F401,E402
+from .registration import make, register_with_gym, registered_ids  # noqa: F401,E402
 
 __version__ = "0.1.0"
 
