@@ -245,6 +245,9 @@ def main():
     while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
         run(CALLS_PER_EPISODE, record=False)
         torch.cuda.synchronize(dev)
+    if state["in_episode"] == CALLS_PER_EPISODE:              # warm-up and timing start at the first call of an episode
+        end_of_episode()
+        reset()
     run(args.warmup, record=False)
     fence()
     episodes_before = state["episode"]
