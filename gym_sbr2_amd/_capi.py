@@ -11,7 +11,9 @@ from . import build as _build
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
-NTRACE = 19          # t, x[14], Kla, EC, reward, done per traced env and call
+NTRACE = 28          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
+(TR_T, TR_X0, TR_KLA, TR_EC, TR_REWARD, TR_DONE, TR_U_DO, TR_U_EC, TR_E_EC, TR_IE_EC, TR_DCV_EC, TR_R_EQI, TR_R_OCI, TR_R_AE,
+ TR_R_EC) = (0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27)
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
@@ -33,7 +35,7 @@ class SbrConfig(C.Structure):
         ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32)]
+        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32)]
 
 
 class SbrError(RuntimeError):
@@ -65,6 +67,7 @@ SYMBOLS = {
     "sbr_get_influent": (C.c_int, [_VP, _VP, _VP]),
     "sbr_eval_rhs": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_draw_normals": (C.c_int, [_VP, _U64, _VP, _VP]),
+    "sbr_draw_scenarios": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_timer_start": (C.c_int, [_VP, _VP]),
     "sbr_timer_stop": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
 }
@@ -91,7 +94,12 @@ def load(build_if_missing=True):
         _build.build_library()
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+        try:
+            fn = getattr(lib, name)    # AttributeError if the .so does not export a declared symbol
+        except AttributeError:
+            if path == _build.LIB:
+                raise
+            continue                   # an A/B variant built from an older source tree may lack newer entry points
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib

@@ -26,92 +26,124 @@
 #include "sbr_device.h"
 
 #define SBR_RESET_BLOCK 256     // k_reset stages 84 KiB of tables in LDS: one block per CU, so make it four waves
-static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB
+static constexpr int kTableDoubles = SBR_NSCEN * SBR_NSERIES * SBR_NSAMP;   // 5376 doubles = 42 KiB (the layout in HBM)
+// In LDS a scenario's block of 14 x 48 doubles is padded to 674: 672 doubles are 1344 dwords = 0 mod 64 banks, so lanes
+// that hold the eight different scenarios (scenario = env id mod 8) would all hit the same bank pair on every table read
+// (8-way conflict); 674 puts scenario s on banks 4s, 4s+1.
+#define SBR_TSTRIDE (SBR_NSERIES * SBR_NSAMP + 2)
+static constexpr int kLdsTableDoubles = 2 * SBR_NSCEN * SBR_TSTRIDE;        // means then stds: 86 272 B
 
 // ------------------------------------------------------------------------------------------- state I/O
 struct SbrBuf {
     double* trace;  // [capacity][SBR_NTRACE][n_trace] or NULL
     int64_t n_trace, trace_cap;
     double* x;      // [14][N]
-    double* ctrl;   // [SBR_NCTRL][N]
+    double* ctrl;   // [R_NROWS][N]
     double* infl;   // [14][N]
     int64_t n;
     int64_t first_env_id;
+#ifdef SBR_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (scripts/probes/step_timeline.py): [waves][8] s_memrealtime ticks
+#endif
 };
+// Diagnostic build -DSBR_STAMPS: lane 0 of every wave records the 100 MHz real-time counter at eight points of k_step.
+// The stamps go to a buffer of their own that nothing else reads; the product build contains none of this.
+#ifdef SBR_STAMPS
+#define SBR_STAMP(k, drain)                                                                                   \
+    do {                                                                                                      \
+        if (drain) __builtin_amdgcn_s_waitcnt(0);                                                             \
+        if (b.stamps != nullptr && (l & 63u) == 0u)                                                           \
+            b.stamps[(uint64_t)((i0 + l) >> 6) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                \
+    } while (0)
+#else
+#define SBR_STAMP(k, drain) do { } while (0)
+#endif
 
-SBR_DEV void load_x(const SbrBuf& b, int64_t i, double (&x)[SBR_NX]) {
+// Addressing.  An env is (i0, l): i0 = first env of the workgroup (wave-uniform, lives in SGPRs), l = threadIdx.x.  Every
+// access is written as (uniform pointer advanced to row and workgroup)[l], so the row arithmetic runs on the scalar unit
+// and the lane contributes one 32-bit offset (global_load v, v_off, s[base:base+1]).  The first version formed a 64-bit
+// address per lane and row: 173 VALU instructions and ~60 VGPRs of k_step.
+#define XROW(j) (b.x + ((int64_t)(j) * b.n + i0))[l]
+#define CTRL(f) (b.ctrl + ((int64_t)(f) * b.n + i0))[l]
+#define INFL(j) (b.infl + ((int64_t)(j) * b.n + i0))[l]
+
+SBR_DEV void load_x(const SbrBuf& b, int64_t i0, uint32_t l, double (&x)[SBR_NX]) {
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) x[j] = b.x[(int64_t)j * b.n + i];
+    for (int j = 0; j < SBR_NX; ++j) x[j] = XROW(j);
 }
-SBR_DEV void store_x(const SbrBuf& b, int64_t i, const double (&x)[SBR_NX]) {
+SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[SBR_NX]) {
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) b.x[(int64_t)j * b.n + i] = x[j];
+    for (int j = 0; j < SBR_NX; ++j) XROW(j) = x[j];
 }
 // INTERNAL controller layout [R_NROWS][N] (the public one of sbr_amd.h is produced by k_export / consumed by k_import):
 //  * the Kla history is a RING: the value of the j-th interval since reset sits in slot (j-1) % 10, where the interval
 //    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten;
-//  * steps, status bits and the done flag share one row (meta = steps*16 + status*2 + done);
+//  * steps, status bits and the done flag share one row (meta = steps*16 + status*2 + done, an integer < 2^31 held in a
+//    double: steps saturate at 2^27 - 1 calls per episode);
 //  * rows only read when tauD != 0 (So[-2], Sno[-2]), only at the end of an episode (Qw) or only by the operating-cost
 //    reward (the running sum of Kla) come last.
 // Per env-step the step kernel reads 18 rows and writes 11 (232 B) instead of 20 + 24 (352 B).
 enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_RING0,
        R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_KSUM, R_NROWS };
-#define CTRL(f) b.ctrl[(int64_t)(f) * b.n + i]
+#define SBR_MAX_STEPS ((1 << 27) - 1)
 
-SBR_DEV long long ring_k(const SbrPar& p, double t) {       // intervals since reset, from the running time
-    double q = (t - p.T_fill) / p.t_delta + 0.5;
+SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since reset, from the running time
+    double q = __builtin_fma(t - p.T_fill, p.inv_t_delta, 0.5);
     if (!(q >= 0.0)) q = 0.0;                                // also catches NaN
-    if (q > 1e15) q = 1e15;
-    return (long long)q;
+    if (q > 2e9) q = 2e9;
+    return (int)q;
 }
-SBR_DEV int ring_slot(long long k, int i) { return (int)((k + i) % SBR_KLA_HIST); }
-SBR_DEV double meta_pack(double steps, int status, bool done) { return steps * 16.0 + (double)(status * 2 + (done ? 1 : 0)); }
-SBR_DEV void meta_unpack(double m, double& steps, int& status, bool& done) {
-    const long long v = (long long)m;
-    done = (v & 1) != 0; status = (int)((v >> 1) & 7); steps = (double)(v >> 4);
+SBR_DEV int ring_wrap(int s) { return s >= SBR_KLA_HIST ? s - SBR_KLA_HIST : s; }       // for 0 <= s < 20
+SBR_DEV double meta_pack(int steps, int status, bool done) { return (double)(steps * 16 + status * 2 + (done ? 1 : 0)); }
+SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done) {
+    const int v = (int)m;
+    done = (v & 1) != 0; status = (v >> 1) & 7; steps = v >> 4;
 }
 
-// Rows the step consumes BEFORE the integration.  So[-2], Sno[-2] only feed the derivative term: read only if tauD != 0.
-SBR_DEV void load_ctl_pre(const SbrPar& p, const SbrBuf& b, int64_t i, SbrCtl& c) {
+// Rows the step consumes BEFORE the integration.  So[-2], Sno[-2] only feed the derivative term (tauD != 0) and the
+// trajectory export's dcv_EC: read only then (need_m2, wave-uniform).
+SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2, SbrCtl& c) {
     c.t = CTRL(R_T); c.so_m1 = CTRL(R_SO_M1); c.sno_m1 = CTRL(R_SNO_M1);
     c.ie_do = CTRL(R_IE_DO); c.ie_ec = CTRL(R_IE_EC); c.ec_last = CTRL(R_EC_LAST);
-    const bool deriv = (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0);            // wave-uniform
-    c.so_m2 = deriv ? CTRL(R_SO_M2) : c.so_m1;
-    c.sno_m2 = deriv ? CTRL(R_SNO_M2) : c.sno_m1;
+    c.so_m2 = need_m2 ? CTRL(R_SO_M2) : c.so_m1;
+    c.sno_m2 = need_m2 ? CTRL(R_SNO_M2) : c.sno_m1;
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
-    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9; c.e_ec = 0.0; c.dcv_ec = 0.0;
 }
 // rows every step rewrites (the ring slot(s), return and meta are written by the caller)
-SBR_DEV void store_ctl(const SbrBuf& b, int64_t i, const SbrCtl& c) {
+SBR_DEV void store_ctl(const SbrBuf& b, int64_t i0, uint32_t l, const SbrCtl& c) {
     CTRL(R_T) = c.t; CTRL(R_SO_M1) = c.so_m1; CTRL(R_SO_M2) = c.so_m2;
     CTRL(R_SNO_M1) = c.sno_m1; CTRL(R_SNO_M2) = c.sno_m2;
     CTRL(R_IE_DO) = c.ie_do; CTRL(R_IE_EC) = c.ie_ec; CTRL(R_EC_LAST) = c.ec_last;
 }
-// whole history, logical order (oldest first), for the given interval count
-SBR_DEV void load_ring(const SbrBuf& b, int64_t i, long long k, double (&hist)[SBR_KLA_HIST]) {
+// whole history, logical order (oldest first), for the given interval count (per-lane slot: the general, slower form)
+SBR_DEV void load_ring(const SbrBuf& b, int64_t i0, uint32_t l, int k, double (&hist)[SBR_KLA_HIST]) {
+    const int kb = k % SBR_KLA_HIST;
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = CTRL(R_RING0 + ring_slot(k, j));
+    for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = CTRL(R_RING0 + ring_wrap(kb + j));
 }
-SBR_DEV void store_ring(const SbrBuf& b, int64_t i, long long k, const double (&hist)[SBR_KLA_HIST]) {
+SBR_DEV void store_ring(const SbrBuf& b, int64_t i0, uint32_t l, int k, const double (&hist)[SBR_KLA_HIST]) {
+    const int kb = k % SBR_KLA_HIST;
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(R_RING0 + ring_slot(k, j)) = hist[j];
+    for (int j = 0; j < SBR_KLA_HIST; ++j) CTRL(R_RING0 + ring_wrap(kb + j)) = hist[j];
 }
 
 // public <-> internal translation (sbr_get_state / sbr_set_state / sbr_get_ctrl_row); only_row < 0 = all rows
 __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double* __restrict__ out, int only_row) {
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
-    double v[SBR_NCTRL], hist[SBR_KLA_HIST], steps;
-    int status; bool done;
+    double v[SBR_NCTRL], hist[SBR_KLA_HIST];
+    int steps, status; bool done;
     const double t = CTRL(R_T);
-    load_ring(b, i, ring_k(p, t), hist);
+    load_ring(b, i0, l, ring_k(p, t), hist);
     meta_unpack(CTRL(R_META), steps, status, done);
     v[SBR_C_T] = t; v[SBR_C_SO_M1] = CTRL(R_SO_M1); v[SBR_C_SO_M2] = CTRL(R_SO_M2);
     v[SBR_C_SNO_M1] = CTRL(R_SNO_M1); v[SBR_C_SNO_M2] = CTRL(R_SNO_M2);
     v[SBR_C_IE_DO] = CTRL(R_IE_DO); v[SBR_C_IE_EC] = CTRL(R_IE_EC); v[SBR_C_EC_LAST] = CTRL(R_EC_LAST);
 #pragma unroll
     for (int j = 0; j < SBR_KLA_HIST; ++j) v[SBR_C_KLA_HIST0 + j] = hist[j];
-    v[SBR_C_QW] = CTRL(R_QW); v[SBR_C_RETURN] = CTRL(R_RET); v[SBR_C_STEPS] = steps;
+    v[SBR_C_QW] = CTRL(R_QW); v[SBR_C_RETURN] = CTRL(R_RET); v[SBR_C_STEPS] = (double)steps;
     v[SBR_C_DONE] = done ? 1.0 : 0.0; v[SBR_C_STATUS] = (double)status; v[SBR_C_KLA_SUM] = CTRL(R_KSUM);
     if (only_row >= 0) {
 #pragma unroll
@@ -122,7 +154,8 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
     }
 }
 __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const double* __restrict__ in) {
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
 #define IN(r) in[(int64_t)(r) * b.n + i]
     const double t = IN(SBR_C_T);
@@ -132,22 +165,36 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
     CTRL(R_T) = t; CTRL(R_SO_M1) = IN(SBR_C_SO_M1); CTRL(R_SO_M2) = IN(SBR_C_SO_M2);
     CTRL(R_SNO_M1) = IN(SBR_C_SNO_M1); CTRL(R_SNO_M2) = IN(SBR_C_SNO_M2);
     CTRL(R_IE_DO) = IN(SBR_C_IE_DO); CTRL(R_IE_EC) = IN(SBR_C_IE_EC); CTRL(R_EC_LAST) = IN(SBR_C_EC_LAST);
-    store_ring(b, i, ring_k(p, t), hist);
+    store_ring(b, i0, l, ring_k(p, t), hist);
     CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN); CTRL(R_KSUM) = IN(SBR_C_KLA_SUM);
-    CTRL(R_META) = meta_pack(IN(SBR_C_STEPS), (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0);
+    double st = IN(SBR_C_STEPS);
+    st = st >= 0.0 ? (st < (double)SBR_MAX_STEPS ? st : (double)SBR_MAX_STEPS) : 0.0;
+    CTRL(R_META) = meta_pack((int)st, (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0);
 #undef IN
+}
+
+// scenario of cfg.random_scenario = 1: uniform over the 8 scenarios (np.random.choice(8, 1), gym_SBR_env4.py:107), Philox
+// stream 2 keyed by the seed of this reset, subsequence = global env id
+SBR_DEV int sbr_scenario_draw(uint64_t seed, uint64_t gid) {
+    uint32_t c[4] = {0u, 2u, (uint32_t)gid, (uint32_t)(gid >> 32)};
+    sbr_philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (int)(c[0] & (SBR_NSCEN - 1));
+}
+
+// copy the influent tables [2][8][14][48] from HBM into the padded LDS image (whole workgroup; caller synchronises)
+SBR_DEV void stage_tables(double* lds, const double* __restrict__ tables) {
+    for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK)
+        lds[k + 2 * (k / (SBR_NSERIES * SBR_NSAMP))] = tables[k];
 }
 
 // influent_mixed for one lane (buffer_tank3.py:68-107): series = mean + std*rnd with ONE rnd vector shared by all series,
 // flow-weighted means, sums accumulated in sample order like python's sum().  ld[1..13]; ld[0] is set by the caller.
-SBR_DEV void influent_lane(const double* lds, bool need_tables, const int32_t* __restrict__ scenario, int default_scenario,
-                           const double* __restrict__ rnd, const double* __restrict__ influent, uint64_t seed, uint64_t gid,
-                           int64_t i, double (&ld)[SBR_NX]) {
+SBR_DEV void influent_lane(const double* lds, bool need_tables, int s, const double* __restrict__ rnd,
+                           const double* __restrict__ influent, uint64_t seed, uint64_t gid, int64_t i, double (&ld)[SBR_NX]) {
     if (need_tables) {
-        int s = scenario ? scenario[i] : default_scenario;
         s = s < 0 ? 0 : (s >= SBR_NSCEN ? SBR_NSCEN - 1 : s);        // never index LDS out of range
-        const double* mu = lds + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
-        const double* sd = lds + kTableDoubles + (int64_t)s * SBR_NSERIES * SBR_NSAMP;
+        const double* mu = lds + s * SBR_TSTRIDE;
+        const double* sd = lds + (SBR_NSCEN + s) * SBR_TSTRIDE;
         double acc[13], sq = 0.0;
 #pragma unroll
         for (int j = 0; j < 13; ++j) acc[j] = 0.0;
@@ -172,6 +219,11 @@ SBR_DEV void influent_lane(const double* lds, bool need_tables, const int32_t* _
     }
     ld[0] = 0.66;                                                    // buffer_tank3.py:107; callers overwrite it
 }
+// which scenario an env is reset with: the caller's tensor, else a device draw (cfg.random_scenario), else the fixed one
+SBR_DEV int pick_scenario(const SbrPar& p, const int32_t* __restrict__ scenario, int fixed, uint64_t seed, uint64_t gid, int64_t i) {
+    if (scenario) return scenario[i];
+    return p.random_scenario ? sbr_scenario_draw(seed, gid) : fixed;
+}
 
 // ------------------------------------------------------------------------------------------- reset
 // SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
@@ -181,25 +233,26 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
                                                     uint64_t seed, const int32_t* __restrict__ scenario,
                                                     const double* __restrict__ rnd, const double* __restrict__ influent,
                                                     const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][14][48]
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][SBR_TSTRIDE]
     const bool need_tables = (influent == nullptr);
     if (need_tables) {
-        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
+        stage_tables(lds, tables);
         __syncthreads();
     }
-    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_RESET_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     if (mask != nullptr && mask[i] == 0) return;
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
 
     double ld[SBR_NX];
-    influent_lane(lds, need_tables, scenario, 6 /* :180 */, rnd, influent, seed, gid, i, ld);
+    influent_lane(lds, need_tables, pick_scenario(p, scenario, 6 /* :180 */, seed, gid, i), rnd, influent, seed, gid, i, ld);
 
     // ---- start state: cfg.x0 / cfg.IV (:197-203), or with CARRY this env's own current state (x0_new / IV_new)
     double x[SBR_NX], x0[SBR_NX];
     double iv = p.IV, qin = p.qin;
     if (CARRY) {
-        load_x(b, i, x0);
+        load_x(b, i0, l, x0);
         iv = x0[0]; qin = p.WV - iv;
         ld[0] = qin / p.T_fill;
     } else {
@@ -208,7 +261,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
         ld[0] = p.load0;                                             // :287
     }
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[j]; b.infl[(int64_t)j * b.n + i] = ld[j]; }
+    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[j]; INFL(j) = ld[j]; }
 
     // ---- fill phase, Sim_filling :1585-1654.  DO-PID at t_start == 0: ie = 0, dcv = 0, set-point 0
     SbrCtl c;
@@ -218,7 +271,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     double kla = p.Kc_DO * e + p.KcI_DO * ie;
     if (kla > p.Kla_max) { kla = p.Kla_max; ie = ie - e * p.dt; }
     if (kla < p.Kla_min) { kla = p.Kla_min; ie = ie - e * p.dt; }
-    sbr_rk4<1>(p, x, p.T_fill, p.fill_rows, kla, 0.0, ld);
+    sbr_rk4<2>(p, x, p.h_fill, p.fill_rows, kla, ld[0], ld);
     c.t = p.T_fill;
     c.so_m2 = x0[8]; c.so_m1 = x[8];
     c.sno_m2 = x0[9]; c.sno_m1 = x[2];                               // :1652 stores Ss in the Sno memory
@@ -227,10 +280,10 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 #pragma unroll
     for (int j = 0; j < SBR_KLA_HIST; ++j) hist[j] = ((SBR_KLA_HIST - 1 - j) % 2 == 0) ? kla : 0.0;   // [0,k]*126, :323
     c.kla_last = kla;
-    store_x(b, i, x);
-    store_ctl(b, i, c);
-    store_ring(b, i, ring_k(p, c.t), hist);          // k = 0: logical order = slot order
-    CTRL(R_RET) = 0.0; CTRL(R_META) = meta_pack(0.0, sbr_status_bits(p, x), false); CTRL(R_QW) = 0.0;
+    store_x(b, i0, l, x);
+    store_ctl(b, i0, l, c);
+    store_ring(b, i0, l, ring_k(p, c.t), hist);      // k = 0: logical order = slot order
+    CTRL(R_RET) = 0.0; CTRL(R_META) = meta_pack(0, sbr_status_bits(p, x), false); CTRL(R_QW) = 0.0;
     double ksum = 0.0;                               // python's sum() over the list [0, k]*126, left to right
     for (int j = 0; j < p.fill_rows / 2; ++j) ksum = ksum + kla;
     CTRL(R_KSUM) = ksum;
@@ -256,99 +309,133 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // xdot start values: 17 doubles per lane, 18 with the operating-cost reward's running sum) are parked in LDS, not in
 // VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and the RK4 loop keeps its registers
 // (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l is at park[j*SBR_BLOCK + l] (conflict-free).
+// The Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally wave-uniform
+// (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the per-lane form.
 #define SBR_NPARK (SBR_KLA_HIST - 1 + 2 + SBR_NXD)
 template <typename OutT, typename ActT, int W, bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
     __shared__ double park[(SBR_NPARK + (OCI ? 1 : 0)) * SBR_BLOCK];
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
-    if (i >= b.n) return;
-    double* my = park + threadIdx.x;          // slot j of this lane: my[j * SBR_BLOCK]
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK;
+    if (i0 + l >= b.n) return;
+    double* my = park + l;                    // slot j of this lane: my[j * SBR_BLOCK]
     double x[SBR_NX];
     SbrCtl c;
-    load_x(b, i, x);
-    load_ctl_pre(p, b, i, c);
-    const long long k0 = ring_k(p, c.t);                  // intervals run before this call
+    SBR_STAMP(0, false);
+    load_x(b, i0, l, x);
+    load_ctl_pre(b, i0, l, (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0) || b.trace != nullptr, c);
+    const int kb = ring_k(p, c.t) % SBR_KLA_HIST;          // ring position of the oldest entry (= slot the next Kla goes to)
+    const int kb_u = __builtin_amdgcn_readfirstlane(kb);
+    const bool ring_uniform = __builtin_amdgcn_ballot_w64(kb != kb_u) == 0ull;
     const double meta0 = CTRL(R_META);
-    const double a0 = (double)action[2 * i], a1 = (double)action[2 * i + 1];     // one 8- or 16-byte load per lane
-    c.kla_last = CTRL(R_RING0 + ring_slot(k0, SBR_KLA_HIST - 1));
-    const double kla_before = c.kla_last;
+    const ActT* act = action + i0 * 2;
+    const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
+    if (ring_uniform) {
+        c.kla_last = CTRL(R_RING0 + ring_wrap(kb_u + SBR_KLA_HIST - 1));
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_slot(k0, j));
+        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_wrap(kb_u + j));
+    } else {
+        c.kla_last = CTRL(R_RING0 + ring_wrap(kb + SBR_KLA_HIST - 1));
+#pragma unroll
+        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_wrap(kb + j));
+    }
+    const double kla_before = c.kla_last;
     my[9 * SBR_BLOCK] = CTRL(R_RET); my[10 * SBR_BLOCK] = meta0;
     SbrX6Lds x6{my + 11 * SBR_BLOCK};
     if (OCI) my[SBR_NPARK * SBR_BLOCK] = CTRL(R_KSUM);    // only this reward keeps the running sum of Kla
     x6.put(x);
+    SBR_STAMP(1, true);                       // every load has returned, the parked values are in LDS
     double t_obs = p.t_cycle, r = 0.0;
     bool dn = true;
     double xa6[SBR_NXD];
-    if (((long long)meta0 & 1) == 0) {    // not done: a finished env waits for sbr_reset (the reference leaves resetting to the caller)
-        double qw = 0.0, hist[SBR_KLA_HIST], steps;
-        int status; bool was_done;
+    if (((int)meta0 & 1) == 0) {          // not done: a finished env waits for sbr_reset (the reference leaves resetting to the caller)
+        double qw = 0.0, hist[SBR_KLA_HIST];
+        int steps, status; bool was_done;
+        SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
+        SBR_STAMP(2, false);
         sbr_run_intervals(p, c, x, a0, a1, x6);
+        SBR_STAMP(3, false);                  // PIDs + RK4 done
 #pragma unroll
         for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * SBR_BLOCK];
         hist[SBR_KLA_HIST - 1] = kla_before;
         x6.get(xa6);
         double ksum = OCI ? my[SBR_NPARK * SBR_BLOCK] : 0.0;
-        r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum);
+        r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum, rp);
+        SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
         // (wave-uniform test: no lane of the wave changed them)
         const bool inert_moved = (x[0] != v0) || (x[1] != si0) || (x[3] != xi0);
         if (__builtin_amdgcn_ballot_w64(inert_moved) != 0ull) {
-            store_x(b, i, x);
+            store_x(b, i0, l, x);
         } else {
 #pragma unroll
-            for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) b.x[(int64_t)j * b.n + i] = x[j];
+            for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) XROW(j) = x[j];
         }
-        store_ctl(b, i, c);
+        store_ctl(b, i0, l, c);
         if (dn && p.terminal) {           // the idle phase appended one more Kla: the logical history moved by n_new + 1
-            store_ring(b, i, k0 + c.n_new, hist);       // rare (once per episode): rewrite the whole ring consistently with t
+            store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
             CTRL(R_QW) = qw;
+        } else if (ring_uniform) {
+            CTRL(R_RING0 + kb_u) = c.knew[0];
+            if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb_u + 1)) = c.knew[1];
         } else {
-            CTRL(R_RING0 + ring_slot(k0, 0)) = c.knew[0];
-            if (c.n_new > 1) CTRL(R_RING0 + ring_slot(k0, 1)) = c.knew[1];
+            CTRL(R_RING0 + kb) = c.knew[0];
+            if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
         }
         meta_unpack(my[10 * SBR_BLOCK], steps, status, was_done);
         CTRL(R_RET) = my[9 * SBR_BLOCK] + r;
-        CTRL(R_META) = meta_pack(steps + 1.0, status | c.st_new, dn);
-        if (b.trace != nullptr && i < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
-            double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + i;
+        CTRL(R_META) = meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn);
+        if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
+            double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
             rec[0] = c.t;
 #pragma unroll
-            for (int j = 0; j < SBR_NX; ++j) rec[(int64_t)(1 + j) * b.n_trace] = x[j];
-            rec[15 * b.n_trace] = c.knew[c.n_new > 1 ? 1 : 0]; rec[16 * b.n_trace] = c.ec_last;
-            rec[17 * b.n_trace] = r; rec[18 * b.n_trace] = dn ? 1.0 : 0.0;
+            for (int j = 0; j < SBR_NX; ++j) rec[(int64_t)(SBR_TR_X0 + j) * b.n_trace] = x[j];
+            rec[SBR_TR_KLA * b.n_trace] = c.knew[c.n_new > 1 ? 1 : 0]; rec[SBR_TR_EC * b.n_trace] = c.ec_last;
+            rec[SBR_TR_REWARD * b.n_trace] = r; rec[SBR_TR_DONE * b.n_trace] = dn ? 1.0 : 0.0;
+            rec[SBR_TR_U_DO * b.n_trace] = c.u_do; rec[SBR_TR_U_EC * b.n_trace] = c.u_ec;
+            rec[SBR_TR_E_EC * b.n_trace] = c.e_ec; rec[SBR_TR_IE_EC * b.n_trace] = c.ie_ec; rec[SBR_TR_DCV_EC * b.n_trace] = c.dcv_ec;
+            // module_reward_EQIOCI.py:60-112: EQI2, and the cost terms over their maxima (Kla = 240, EC = 0.0005 throughout)
+            const double td = 0.002 / 24;
+            const double ae_max = 1.32 * (240 * 11) * td * (8 / ((td * 11) * 1.8 * 1000));
+            const double ec_max = p.EC_conc * (0.0005 * 11) * td / ((td * 11) * 1000);
+            const double ae2 = rp.ae / ae_max, ec2 = rp.ec / ec_max;
+            rec[SBR_TR_R_EQI * b.n_trace] = rp.eqi2; rec[SBR_TR_R_OCI * b.n_trace] = ae2 + ec2;
+            rec[SBR_TR_R_AE * b.n_trace] = ae2; rec[SBR_TR_R_EC * b.n_trace] = ec2;
         }
     } else {
         x6.get(xa6);
     }
-    if (reward) reward[i] = (OutT)r;
-    if (done) done[i] = dn ? 1 : 0;
-    if (obs) sbr_write_obs<OutT>(obs + i * SBR_NOBS, 1, t_obs, x, xa6, x);
-    if (state) sbr_write_state<OutT>(state + i * SBR_NSTATE, 1, t_obs, x);
+    SBR_STAMP(5, false);                      // state stores issued
+    if (reward) (reward + i0)[l] = (OutT)r;
+    if (done) (done + i0)[l] = dn ? 1 : 0;
+    if (obs) sbr_write_obs<OutT>((obs + i0 * SBR_NOBS) + l * SBR_NOBS, 1, t_obs, x, xa6, x);
+    if (state) sbr_write_state<OutT>((state + i0 * SBR_NSTATE) + l * SBR_NSTATE, 1, t_obs, x);
+    SBR_STAMP(6, false);                      // output stores issued
+    SBR_STAMP(7, true);                       // every store acknowledged
 }
 
 // ------------------------------------------------------------------------------------------- rollout
 template <bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
     double x[SBR_NX], xa6[SBR_NXD], hist[SBR_KLA_HIST];
     SbrCtl c;
     SbrX6Reg x6;
-    load_x(b, i, x);
-    load_ctl_pre(p, b, i, c);
-    c.so_m2 = CTRL(R_SO_M2); c.sno_m2 = CTRL(R_SNO_M2);
-    load_ring(b, i, ring_k(p, c.t), hist);
+    SbrRewardParts rp;
+    load_x(b, i0, l, x);
+    load_ctl_pre(b, i0, l, true, c);
+    load_ring(b, i0, l, ring_k(p, c.t), hist);
     c.kla_last = hist[SBR_KLA_HIST - 1];
-    double ret = CTRL(R_RET), steps, qw = CTRL(R_QW), ksum = OCI ? CTRL(R_KSUM) : 0.0;
-    int status; bool finished;
+    double ret = CTRL(R_RET), qw = CTRL(R_QW), ksum = OCI ? CTRL(R_KSUM) : 0.0;
+    int steps, status; bool finished;
     meta_unpack(CTRL(R_META), steps, status, finished);
     double acc = 0.0;
     for (int32_t s = 0; s < n_steps; ++s) {
@@ -360,15 +447,16 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32
         bool dn;
         sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
-        const double r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum);
-        acc += r; ret += r; steps += 1.0; status |= c.st_new;
+        const double r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum, rp);
+        acc += r; ret += r; status |= c.st_new;
+        if (steps < SBR_MAX_STEPS) steps += 1;
         if (dn) finished = true;
     }
-    store_x(b, i, x);
-    store_ctl(b, i, c);
+    store_x(b, i0, l, x);
+    store_ctl(b, i0, l, c);
     // the ring is addressed by the interval count recovered from t: store the logical history consistently with the final t
     // (the idle phase's extra Kla does not advance t; k_export reads with the same rule)
-    store_ring(b, i, ring_k(p, c.t), hist);
+    store_ring(b, i0, l, ring_k(p, c.t), hist);
     CTRL(R_RET) = ret; CTRL(R_META) = meta_pack(steps, status, finished); CTRL(R_QW) = qw;
     if (OCI) CTRL(R_KSUM) = ksum;                     // like k_step: only this reward maintains the row
     if (returns) returns[i] = acc;
@@ -384,24 +472,26 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const bool need_tables = (influent == nullptr);
     if (need_tables) {
-        for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK) lds[k] = tables[k];
+        stage_tables(lds, tables);
         __syncthreads();
     }
-    const int64_t i = (int64_t)blockIdx.x * SBR_RESET_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_RESET_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     if (mask != nullptr && mask[i] == 0) return;
     double ld[SBR_NX], x0[SBR_NX];
-    influent_lane(lds, need_tables, scenario, 0, rnd, influent, seed, (uint64_t)(b.first_env_id + i), i, ld);
-    if (CARRY) load_x(b, i, x0);
+    const uint64_t gid = (uint64_t)(b.first_env_id + i);
+    influent_lane(lds, need_tables, pick_scenario(p, scenario, 0 /* :104 */, seed, gid, i), rnd, influent, seed, gid, i, ld);
+    if (CARRY) load_x(b, i0, l, x0);
     else {
 #pragma unroll
         for (int j = 0; j < SBR_NX; ++j) x0[j] = p.x0[j];
-        store_x(b, i, x0);
+        store_x(b, i0, l, x0);
     }
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) b.infl[(int64_t)j * b.n + i] = ld[j];
+    for (int j = 0; j < SBR_NX; ++j) INFL(j) = ld[j];
     CTRL(R_T) = 0.0; CTRL(R_RET) = 0.0; CTRL(R_QW) = 0.0;
-    CTRL(R_META) = meta_pack(0.0, sbr_status_bits(p, x0), true);     // inert for sbr_step: this handle runs whole cycles
+    CTRL(R_META) = meta_pack(0, sbr_status_bits(p, x0), true);       // inert for sbr_step: this handle runs whole cycles
     if (obs) {
         const double cod = (x0[1] + ld[1]) + (x0[2] + ld[2]) + (x0[3] + ld[3]) + (x0[4] + ld[4]) + (x0[5] + ld[5]) +
                            (x0[6] + ld[6]) + (x0[7] + ld[7]);
@@ -413,24 +503,33 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
 template <typename OutT, typename ActT>
 __global__ __launch_bounds__(SBR_BLOCK) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {
-    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     double x[SBR_NX], ld[SBR_NX], o3[3];
-    load_x(b, i, x);
+    load_x(b, i0, l, x);
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) ld[j] = b.infl[(int64_t)j * b.n + i];
+    for (int j = 0; j < SBR_NX; ++j) ld[j] = INFL(j);
     ld[0] = (p.WV - x[0]) / p.t_ph[0];                                // Qin / (t_cycle * t_ratio[0]), gym_SBR_env2.py:144
-    const double st0 = (double)sbr_status_bits(p, x);
+    const int st0 = sbr_status_bits(p, x);
     const double r = sbr_cycle_env(p, x, ld, (double)action[3 * i], (double)action[3 * i + 1], (double)action[3 * i + 2], o3,
                                    diag ? diag + i * SBR_NCYC_DIAG : nullptr, 1);
-    store_x(b, i, x);
+    store_x(b, i0, l, x);
     CTRL(R_RET) = CTRL(R_RET) + r; CTRL(R_T) = p.t_cycle;
-    CTRL(R_META) = meta_pack(1.0, (int)st0 | sbr_status_bits(p, x), true);
+    CTRL(R_META) = meta_pack(1, st0 | sbr_status_bits(p, x), true);
     if (obs) { obs[i * 3 + 0] = (OutT)o3[0]; obs[i * 3 + 1] = (OutT)o3[1]; obs[i * 3 + 2] = (OutT)o3[2]; }
     if (reward) reward[i] = (OutT)r;
 }
 
+// the scenario draw of cfg.random_scenario, for tests and callers that want to know it
+__global__ __launch_bounds__(SBR_BLOCK) void k_scenarios(SbrBuf b, uint64_t seed, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i < b.n) out[i] = sbr_scenario_draw(seed, (uint64_t)(b.first_env_id + i));
+}
+
 #undef CTRL
+#undef XROW
+#undef INFL
 
 // ------------------------------------------------------------------------------------------- stats
 // {sum, min, max, count} of a per-env vector: butterfly over the 64 lanes of each wave (DPP/swizzle via
@@ -482,6 +581,11 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_stats(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------- helpers
+__global__ __launch_bounds__(SBR_BLOCK) void k_fill(double* __restrict__ dst, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 __global__ __launch_bounds__(SBR_BLOCK) void k_rhs(SbrPar p, int32_t kind, int64_t n, const double* __restrict__ x,
                                                   const double* __restrict__ kla, const double* __restrict__ ec,
                                                   const double* __restrict__ loading, double* __restrict__ dx) {
@@ -522,7 +626,7 @@ struct sbr_env {
     std::string err;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;      // creation errors are reported per calling thread (sbr_last_error(NULL))
 
 static int fail(sbr_env* e, int code, const std::string& msg) {
     if (e) e->err = msg; else g_create_err = msg;
@@ -534,6 +638,8 @@ static int fail(sbr_env* e, int code, const std::string& msg) {
         if (_s != hipSuccess)                                                                         \
             return fail(e, SBR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));           \
     } while (0)
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + SBR_BLOCK - 1) / SBR_BLOCK)); }
 
 // Entry points run on the handle's device and leave the caller's current device as they found it (a process may drive
 // several GPUs, and torch tracks the current device itself).
@@ -550,6 +656,19 @@ struct DeviceGuard {
 #define ON_DEVICE(e)                      \
     DeviceGuard _guard((e)->device);      \
     HIP_TRY(e, _guard.status)
+
+// smallest double s with (int)(s / dt) >= rows, i.e. whose IEEE quotient by dt reaches rows: start at rows*dt and step
+// through the neighbouring doubles (the quotient is monotonic in s; a handful of steps at most)
+static double rows_threshold(double dt, int rows) {
+    double s = (double)rows * dt;
+    for (int it = 0; it < 64 && (int)(s / dt) < rows; ++it) s = std::nextafter(s, INFINITY);
+    for (int it = 0; it < 64; ++it) {
+        const double below = std::nextafter(s, 0.0);
+        if ((int)(below / dt) < rows) break;
+        s = below;
+    }
+    return s;
+}
 
 static void derive_params(const sbr_config& c, SbrPar& p) {
     p.muH = c.muH; p.Ks = c.Ks; p.Koh = c.Koh; p.Kno = c.Kno; p.bH = c.bH; p.eta_g = c.eta_g; p.eta_h = c.eta_h;
@@ -574,12 +693,19 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.biomass_setpoint = c.biomass_setpoint; p.Qeff = c.Qeff; p.settler_area = c.settler_area;
     p.settler_vmax = c.settler_vmax;
     memcpy(p.x0, c.x0, sizeof p.x0);
-    p.muH_etag = c.muH * c.eta_g;
+    p.f1a = c.kh / c.muH; p.f1b = c.Ks * (c.kh / c.muH);
+    p.f2a = 1.0 / c.kh; p.f2b = c.Koh / c.kh;
+    p.f4a = 1.0 / c.muA; p.f4b = c.Knh / c.muA;
+    p.KohEtag = c.Koh * c.eta_g; p.etah_g = c.eta_h / c.eta_g;
     for (int k = 0; k < 8; ++k) p.t_ph[k] = c.t_cycle * c.t_ratio[k];
     p.cyc_Kc = c.cyc_Kc; p.cyc_KcI = c.cyc_Kc / c.cyc_tauI; p.cyc_KcD = c.cyc_Kc * c.cyc_tauD; p.cyc_dt = c.cyc_dt;
     p.substeps = c.substeps; p.terminal = c.terminal;
     p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
     p.reward_kind = c.reward_kind;
+    p.random_scenario = c.random_scenario;
+    p.inv_dt = 1.0 / c.dt; p.inv_t_delta = 1.0 / c.t_delta; p.inv_substeps = 1.0 / (double)c.substeps;
+    p.inv_cyc_dt = 1.0 / c.cyc_dt; p.h_fill = c.T_fill / (double)p.fill_rows;
+    p.rows10_min = rows_threshold(c.dt, 10); p.rows9_min = rows_threshold(c.dt, 9);
 }
 
 template <typename OutT, typename ActT, bool OCI>
@@ -627,7 +753,7 @@ int sbr_default_config(sbr_config* c) {
                                       13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
                                       3.790463057094611};
     memcpy(c->x0, x0, sizeof x0);
-    c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->reward_kind = 0; c->act_f64 = 0;
+    c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->reward_kind = 0; c->act_f64 = 0; c->random_scenario = 0;
     return SBR_OK;
 }
 
@@ -663,6 +789,10 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     if (!(c.T3_0 - c.T_fill > c.t_delta) || !(c.T3_end - c.T3_0 > c.t_delta) || !(c.T4_end - c.T3_end > c.t_delta))
         bad = "phases 2, 3 and 4 must each be longer than t_delta";
     if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0) || !(c.cyc_tauI != 0) || !(c.cyc_dt > 0)) bad = "tauI must be non-zero, cyc_dt positive";
+    // the rate constants that are folded into the Monod denominators (sbr_rates) must be positive and finite
+    if (!(c.muH > 0 && c.muH < 1e300) || !(c.muA > 0 && c.muA < 1e300) || !(c.kh > 0 && c.kh < 1e300) ||
+        !(c.eta_g > 0 && c.eta_g < 1e300)) bad = "muH, muA, kh and eta_g must be positive";
+    if (c.substeps > (1 << 20)) bad = "substeps out of range";
     for (int k = 0; k < 8; ++k) if (!(c.t_ratio[k] > 0)) bad = "t_ratio entries must be positive";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }
     derive_params(c, e->par);
@@ -693,14 +823,14 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     CREATE_TRY(hipMemset(e->buf.ctrl, 0, R_NROWS * nb));
     CREATE_TRY(hipMemset(e->buf.infl, 0, SBR_NX * nb));
     // an env is unusable until its first reset: mark everything done so that step() is a no-op until then
-    {
-        std::vector<double> ones((size_t)n_envs, 1.0);        // meta = steps*16 + status*2 + done  =>  1.0 = "done"
-        CREATE_TRY(hipMemcpy(e->buf.ctrl + (size_t)R_META * n_envs, ones.data(), nb, hipMemcpyHostToDevice));
-    }
+    // (meta = steps*16 + status*2 + done  =>  1.0 = "done"); filled on the device, no host staging buffer
+    hipLaunchKernelGGL(k_fill, grid_for(n_envs), dim3(SBR_BLOCK), 0, nullptr, e->buf.ctrl + (size_t)R_META * n_envs, n_envs, 1.0);
+    CREATE_TRY(hipGetLastError());
+    CREATE_TRY(hipDeviceSynchronize());
     CREATE_TRY(hipEventCreate(&e->ev0));
     CREATE_TRY(hipEventCreate(&e->ev1));
     {
-        const int lds_bytes = 2 * kTableDoubles * (int)sizeof(double);     // 84 KiB of dynamic LDS: above the 64 KiB default
+        const int lds_bytes = kLdsTableDoubles * (int)sizeof(double);      // 84 KiB of dynamic LDS: above the 64 KiB default
         const void* fns[4] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
                               reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>)};
         for (const void* fn : fns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -739,8 +869,6 @@ int sbr_set_influent_tables(sbr_env* e, const double* means, const double* stds)
     return SBR_OK;
 }
 
-static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + SBR_BLOCK - 1) / SBR_BLOCK)); }
-
 static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scenario, const double* rnd,
                       const double* influent, const uint8_t* mask, void* obs, void* stream) {
     if (!e) return SBR_ERR_INVALID;
@@ -748,7 +876,7 @@ static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scen
         return fail(e, SBR_ERR_INVALID, "sbr_reset: no influent given and sbr_set_influent_tables was never called");
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
+    const size_t lds = influent ? 0 : kLdsTableDoubles * sizeof(double);
     const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
 #define RESET_LAUNCH(T, C) hipLaunchKernelGGL((k_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
                                               influent, mask, (T*)obs)
@@ -798,7 +926,7 @@ int sbr_cycle_reset(sbr_env* e, uint64_t seed, const int32_t* scenario, const do
         return fail(e, SBR_ERR_INVALID, "sbr_cycle_reset: no influent given and sbr_set_influent_tables was never called");
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = influent ? 0 : 2 * kTableDoubles * sizeof(double);
+    const size_t lds = influent ? 0 : kLdsTableDoubles * sizeof(double);
     const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
 #define CRESET(T, C) hipLaunchKernelGGL((k_cycle_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
                                         influent, mask, (T*)obs)
@@ -913,6 +1041,18 @@ int sbr_draw_normals(sbr_env* e, uint64_t seed, double* out, void* stream) {
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }
+
+int sbr_draw_scenarios(sbr_env* e, uint64_t seed, int32_t* out, void* stream) {
+    if (!e || !out) return fail(e, SBR_ERR_INVALID, "sbr_draw_scenarios: NULL argument");
+    ON_DEVICE(e);
+    hipLaunchKernelGGL(k_scenarios, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->buf, seed, out);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+#ifdef SBR_STAMPS
+int sbr_set_stamps(sbr_env* e, unsigned long long* buf) { if (!e) return SBR_ERR_INVALID; e->buf.stamps = buf; return SBR_OK; }
+#endif
 
 int sbr_timer_start(sbr_env* e, void* stream) {
     if (!e) return SBR_ERR_INVALID;

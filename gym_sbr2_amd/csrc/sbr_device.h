@@ -48,10 +48,20 @@ struct SbrPar {
     // terminal
     double biomass_setpoint, Qeff, settler_area, settler_vmax;
     double x0[SBR_NX];
-    double muH_etag;     // muH * eta_g
+    // kinetics folded into the Monod denominators (sbr_rates): d1 = f1a Ss + f1b = (Ks + Ss) kh/muH,
+    // d2 = f2a So + f2b = (Koh + So)/kh, d4 = f4a Snh + f4b = (Knh + Snh)/muA
+    double f1a, f1b, f2a, f2b, f4a, f4b;
+    double KohEtag;      // Koh * eta_g
+    double etah_g;       // eta_h / eta_g
     double t_ph[8];      // phase lengths t_cycle * t_ratio[k]                 (SBR_model_FB.py:18-27)
     double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
-    int32_t substeps, terminal, fill_rows, reward_kind;
+    // reciprocals of wave-uniform divisors, taken once on the host (an IEEE f64 division is ~19 issue slots on the device)
+    double inv_dt, inv_t_delta, inv_substeps, inv_cyc_dt, h_fill;
+    // len(t_range) = int(span/dt) of a control interval (:1339, :1384) is 10 iff span >= rows10_min and 9 iff
+    // rows9_min <= span < rows10_min: the smallest doubles whose IEEE quotient by dt reaches 10.0 / 9.0 (found on the
+    // host by stepping through neighbouring doubles), so the common case costs two comparisons and stays exact
+    double rows10_min, rows9_min;
+    int32_t substeps, terminal, fill_rows, reward_kind, random_scenario;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -66,129 +76,106 @@ SBR_DEV double sbr_rcp(double d) {
     const double e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
-
-// Conversion rates r[i] of the 11 reacting components (Si, Xi and V do not react), incl. aeration.
-// Process rates :1660-1685, combination :1731-1755.  The reference's ten quotients are evaluated with SEVEN shared
-// reciprocals: So/(Koh+So) and Koh/(Koh+So) share one, and (Xs/Xbh)/(Kx + Xs/Xbh) is written Xs/(Kx*Xbh + Xs).
-// Equal coefficients are factored (nu2_1 = nu2_2, nu4_4 = nu4_5, ...).  Parity is to tolerance, not bitwise.
-template <bool WITH_V>
-SBR_DEV double sbr_conversion(const SbrPar& p, const double (&x)[SBR_NX], double kla, double (&r)[SBR_NX]) {
-    const double ss = x[2], xs = x[4], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10], snd = x[11],
-                 xnd = x[12];
-#ifndef SBR_BATCH_RCP
-#define SBR_BATCH_RCP 1
-#endif
-#ifndef SBR_RHO8_DIRECT
-#define SBR_RHO8_DIRECT 1
-#endif
-#if SBR_BATCH_RCP
-    // v_rcp_f64 issues in ~32 cycles on gfx950 (8 FMA slots; measured: 392 + 28 x 32 cycles = the 1.02 us of a substep), so the
-    // reciprocals are taken from ONE: R = 1/(d1 d2 ... d6), then 1/dk = R x (product of the others), peeled off with two
-    // multiplications each (Montgomery's trick): 15 multiplications + 1 reciprocal instead of 6 reciprocals.  Rounding
-    // grows to ~7 ulp (parity bounds are >= 1e-11 relative); the product (~1e9) cannot over- or underflow for finite states.
-    // The reference's seventh quotient, Xnd/Xs in rho8 = (Xnd/Xs) rho7 (:1685), needs no reciprocal: rho7 carries the factor
-    // Xs, so rho8 = Xnd x (rho7 / Xs) is formed from the common factor c7 (SBR_RHO8_DIRECT; same value to rounding, and the
-    // continuous extension at Xs -> 0 where the reference evaluates 0/0).  Measured: -1.6 % per k_step launch, -4 % fused.
-    const double d1 = p.Ks + ss, d2 = p.Koh + so, d3 = p.Kno + sno, d4 = p.Knh + snh, d5 = p.Koa + so;
-    const double d6 = __builtin_fma(p.Kx, xbh, xs), d7 = xs;
-#if SBR_BATCH_RCP == 2
-    // two independent chains (4 + 3 denominators): one more reciprocal, but half the serial dependency depth
-    const double q2 = d1 * d2, q3 = q2 * d3;
-    double Ra = sbr_rcp(q3 * d4);
-    const double rd = Ra * q3; Ra = Ra * d4;
-    const double rc = Ra * q2; Ra = Ra * d3;
-    const double rb = Ra * d1, ra = Ra * d2;
-    const double rv = WITH_V ? sbr_rcp(x[0]) : 0.0;
-    const double s2 = d5 * d6;
-    double Rb = sbr_rcp(s2 * d7);
-    const double rg = Rb * s2; Rb = Rb * d7;
-    const double re = Rb * d6, rf = Rb * d5;
-#else
-    const double p2 = d1 * d2, p3 = p2 * d3, p4 = p3 * d4, p5 = p4 * d5, p6 = p5 * d6;
-    double R, rv = 0.0;
-#if SBR_RHO8_DIRECT
-    // rho8 = (Xnd/Xs) rho7 and rho7 = kh Xs/(Kx Xbh + Xs) [..] Xbh: Xs cancels, so 1/Xs is not needed at all
-    if (WITH_V) {
-        R = sbr_rcp(p6 * x[0]);
-        rv = R * p6; R = R * x[0];
-    } else {
-        R = sbr_rcp(p6);
-    }
-    (void)d7;
-#else
-    if (WITH_V) {                        // dosing / fill: 1/V for the dilution terms rides in the same batch
-        const double p7 = p6 * d7;
-        R = sbr_rcp(p7 * x[0]);
-        rv = R * p7; R = R * x[0];
-    } else {
-        R = sbr_rcp(p6 * d7);
-    }
-    const double rg = R * p6; R = R * d7;
-#endif
-    const double rf = R * p5; R = R * d6;
-    const double re = R * p4; R = R * d5;
-    const double rd = R * p3; R = R * d4;
-    const double rc = R * p2; R = R * d3;
-    const double rb = R * d1, ra = R * d2;
-#endif
-#else
-    const double ra = sbr_rcp(p.Ks + ss);
-    const double rb = sbr_rcp(p.Koh + so);
-    const double rc = sbr_rcp(p.Kno + sno);
-    const double rd = sbr_rcp(p.Knh + snh);
-    const double re = sbr_rcp(p.Koa + so);
-    const double rf = sbr_rcp(__builtin_fma(p.Kx, xbh, xs));
-    const double rg = sbr_rcp(xs);
-    const double rv = WITH_V ? sbr_rcp(x[0]) : 0.0;
-#endif
-    const double m_so = so * rb;                     // So/(Koh+So)
-    const double inox = (p.Koh * rb) * (sno * rc);   // Koh/(Koh+So) * Sno/(Kno+Sno)
-    const double g = (ss * ra) * xbh;                // Ss/(Ks+Ss) * Xbh
-    const double rho1 = p.muH * g * m_so;
-    const double rho2 = p.muH_etag * g * inox;
-    const double rho3 = p.muA * (snh * rd) * (so * re) * xba;
-    const double rho4 = p.bH * xbh;
-    const double rho5 = p.bA * xba;
-    const double rho6 = p.ka * snd * xbh;
-#if SBR_RHO8_DIRECT && SBR_BATCH_RCP == 1
-    const double c7 = p.kh * rf * __builtin_fma(p.eta_h, inox, m_so) * xbh;
-    const double rho7 = xs * c7, rho8 = xnd * c7;
-#else
-    const double rho7 = p.kh * (xs * rf) * __builtin_fma(p.eta_h, inox, m_so) * xbh;
-    const double rho8 = (xnd * rg) * rho7;
-#endif
-    const double s12 = rho1 + rho2, s45 = rho4 + rho5;
-    r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
-    r[2] = __builtin_fma(p.n2_12, s12, rho7);
-    r[4] = __builtin_fma(p.n4_45, s45, -rho7);
-    r[5] = s12 - rho4;
-    r[6] = rho3 - rho5;
-    r[7] = p.n7_45 * s45;
-    r[8] = p.n8_1 * rho1 + p.n8_3 * rho3 + kla * (p.So_sat - so);
-    r[9] = p.n9_2 * rho2 + p.n9_3 * rho3;
-    r[10] = p.n10_12 * s12 + p.n10_3 * rho3 + rho6;
-    r[11] = rho8 - rho6;
-    r[12] = __builtin_fma(p.n12_45, s45, -rho8);
-    r[13] = p.n13_1 * rho1 + p.n13_2 * rho2 + p.n13_3 * rho3 + p.n13_6 * rho6;
-    return rv;                           // 1/V if WITH_V
+// the same Newton step from a reciprocal that is already within ~1e-7 of 1/d (1/V while carbon is dosed: V moves by
+// 3e-8 of itself per substep, so e^3 ~ 1e-23)
+SBR_DEV double sbr_rcp_refine(double d, double r) {
+    const double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 
-// Right-hand sides.  KIND 0: reaction_dxdt :1658-1787 (dosing ec, dilution ec/V)
-//                    KIND 1: filling_dxdt :1424-1583 at EC = 0 (loading vector ld, ld[0] = inflow)
-//                    KIND 2: idle_dxdt :2424-2552 (conversion only)
-//                    KIND 3: reaction with ec == 0 for every lane of the wave: V, Si, Xi are constant
+// The components that feed back into the process rates, and therefore have to exist at every RK4 stage:
+// Ss Xs Xbh Xba So Sno Snh Snd Xnd.  V, Si, Xi and Salk never enter a rate; Xp does not either.
+#define SBR_NA 9
+enum { A_SS = 0, A_XS, A_XBH, A_XBA, A_SO, A_SNO, A_SNH, A_SND, A_XND };
+SBR_DEV void sbr_gather(const double (&x)[SBR_NX], double (&a)[SBR_NA]) {
+    a[A_SS] = x[2]; a[A_XS] = x[4]; a[A_XBH] = x[5]; a[A_XBA] = x[6]; a[A_SO] = x[8]; a[A_SNO] = x[9]; a[A_SNH] = x[10];
+    a[A_SND] = x[11]; a[A_XND] = x[12];
+}
+SBR_DEV void sbr_scatter(const double (&a)[SBR_NA], double (&x)[SBR_NX]) {
+    x[2] = a[A_SS]; x[4] = a[A_XS]; x[5] = a[A_XBH]; x[6] = a[A_XBA]; x[8] = a[A_SO]; x[9] = a[A_SNO]; x[10] = a[A_SNH];
+    x[11] = a[A_SND]; x[12] = a[A_XND];
+}
+
+// What the other derivatives are made of (the known-answer kernel k_rhs rebuilds all 14 from it; the integrator only
+// needs s45): rho1, rho2, rho3, rho6 and rho4 + rho5.
+struct SbrRho { double rho1, rho2, rho3, rho6, s45; };
+
+// Conversion rates of the nine feedback components, incl. aeration.  Process rates :1660-1685, combination :1731-1755.
+//
+// fp64 VALU issue is the bound of every stepping kernel (4 cycles per instruction and wave, one wave per SIMD already
+// saturates it), so this function is written for INSTRUCTION COUNT, 55 + one v_rcp_f64 (the first version: 92 + 7):
+//  * the reference's ten quotients need six denominators; all six reciprocals come from ONE v_rcp_f64 of their product,
+//    peeled apart as a tree (pairs first): 5 + 7 multiplications, dependency depth 3 + 3;
+//  * the leading constants of the rates (muH, muA, kh, eta_g) are folded into the denominators on the host - a
+//    denominator (K + x)*c costs one FMA instead of one ADD, i.e. nothing - so that rho1, rho2, rho3, rho7 come out of
+//    the reciprocals already scaled: d1 = (Ks+Ss) kh/muH, d2 = (Koh+So)/kh, d4 = (Knh+Snh)/muA;
+//  * So/(Koh+So) and Koh/(Koh+So) share 1/d2, (Xs/Xbh)/(Kx + Xs/Xbh) is Xs/(Kx Xbh + Xs), and rho8 = (Xnd/Xs) rho7
+//    needs no 1/Xs because rho7 carries the factor Xs (also the continuous extension at Xs -> 0, where the reference
+//    evaluates 0/0);
+//  * rho4, rho5, rho6 are never formed: they enter the derivatives through FMAs.
+// 1/V is deliberately NOT part of the batch (see sbr_rk4): the six reciprocals of a lane are the same whether or not a
+// wave-mate doses carbon, so an env's arithmetic does not depend on which envs share its wavefront.
+// Parity is to tolerance, not bitwise (RHS known answers within 2e-15 relative).
+SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, double kla_sat, double (&k)[SBR_NA],
+                       SbrRho& o) {
+    const double ss = a[A_SS], xs = a[A_XS], xbh = a[A_XBH], xba = a[A_XBA], so = a[A_SO], sno = a[A_SNO], snh = a[A_SNH],
+                 snd = a[A_SND], xnd = a[A_XND];
+    const double d1 = __builtin_fma(ss, p.f1a, p.f1b);        // (Ks + Ss) kh/muH
+    const double d2 = __builtin_fma(so, p.f2a, p.f2b);        // (Koh + So)/kh
+    const double d3 = p.Kno + sno;
+    const double d4 = __builtin_fma(snh, p.f4a, p.f4b);       // (Knh + Snh)/muA
+    const double d5 = p.Koa + so;
+    const double d6 = __builtin_fma(p.Kx, xbh, xs);
+    const double A = d1 * d2, B = d4 * d5, Cc = d3 * d6, AB = A * B;
+    const double R = sbr_rcp(AB * Cc);
+    const double rC = R * AB, rAB = R * Cc;
+    const double rA = rAB * B;                                 // muH / ((Ks+Ss)(Koh+So))
+    const double rB = rAB * A;                                 // muA / ((Knh+Snh)(Koa+So))
+    const double rc = rC * d6, rf = rC * d3, rb = rA * d1;     // 1/(Kno+Sno), 1/(Kx Xbh + Xs), kh/(Koh+So)
+    const double G = (ss * xbh) * rA;
+    const double rho1 = G * so;                                // muH Ss/(Ks+Ss) So/(Koh+So) Xbh
+    const double kw = p.KohEtag * (sno * rc);                  // eta_g Koh Sno/(Kno+Sno)
+    const double rho2 = G * kw;                                // muH Ss/(Ks+Ss) Koh/(Koh+So) Sno/(Kno+Sno) eta_g Xbh
+    const double E = __builtin_fma(p.etah_g, kw * rb, so * rb);   // kh [So/(Koh+So) + eta_h Koh/(Koh+So) Sno/(Kno+Sno)]
+    const double c7 = (rf * E) * xbh;                          // rho7 / Xs
+    const double rho7 = xs * c7, rho8 = xnd * c7;
+    const double rho3 = ((snh * so) * rB) * xba;               // muA Snh/(Knh+Snh) So/(Koa+So) Xba
+    const double t4 = p.bH * xbh;                              // rho4
+    const double s45 = __builtin_fma(p.bA, xba, t4);           // rho4 + rho5
+    const double z = snd * xbh;                                // rho6 / ka
+    const double s12 = rho1 + rho2;
+    k[A_SS] = __builtin_fma(p.n2_12, s12, rho7);
+    k[A_XS] = __builtin_fma(p.n4_45, s45, -rho7);
+    k[A_XBH] = s12 - t4;
+    k[A_XBA] = __builtin_fma(-p.bA, xba, rho3);
+    k[A_SO] = __builtin_fma(p.n8_1, rho1, __builtin_fma(p.n8_3, rho3, __builtin_fma(-kla, so, kla_sat)));   // + kla (So_sat - So)
+    k[A_SNO] = __builtin_fma(p.n9_2, rho2, p.n9_3 * rho3);
+    k[A_SNH] = __builtin_fma(p.n10_12, s12, __builtin_fma(p.n10_3, rho3, p.ka * z));
+    k[A_SND] = __builtin_fma(-p.ka, z, rho8);
+    k[A_XND] = __builtin_fma(p.n12_45, s45, -rho8);
+    o.rho1 = rho1; o.rho2 = rho2; o.rho3 = rho3; o.rho6 = p.ka * z; o.s45 = s45;
+}
+
+// All 14 derivatives of one state, for the known-answer kernel only.  KIND 0: reaction_dxdt :1658-1787 (dosing ec,
+// dilution ec/V), 1: filling_dxdt :1424-1583 at EC = 0 (loading vector ld, ld[0] = inflow), 2: idle_dxdt :2424-2552.
 template <int KIND>
 SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, double ec, const double (&ld)[SBR_NX],
                      double (&d)[SBR_NX]) {
-    double r[SBR_NX];
-    const double rv = sbr_conversion<(KIND == 0 || KIND == 1)>(p, x, kla, r);
+    double a[SBR_NA], k[SBR_NA], r[SBR_NX];
+    SbrRho o;
+    sbr_gather(x, a);
+    sbr_rates(p, a, kla, kla * p.So_sat, k, o);
+    r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
+    sbr_scatter(k, r);
+    r[7] = p.n7_45 * o.s45;
+    r[13] = p.n13_1 * o.rho1 + p.n13_2 * o.rho2 + p.n13_3 * o.rho3 + p.n13_6 * o.rho6;
     if (KIND == 0) {
-        const double q = ec * rv;
+        const double q = ec * sbr_rcp(x[0]);
         d[0] = ec;
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (i == 2 ? (p.EC_conc - x[i]) : (-x[i]));
     } else if (KIND == 1) {
-        const double q = ld[0] * rv;
+        const double q = ld[0] * sbr_rcp(x[0]);
         d[0] = ld[0];
 #pragma unroll
         for (int i = 1; i < SBR_NX; ++i) d[i] = r[i] + q * (ld[i] - x[i]);
@@ -198,28 +185,97 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
     }
 }
 
-// Classical RK4, n equal substeps over `span`; autonomous inside a span (Kla, EC held).  Low-storage
-// form: x, the running combination and one stage vector are live (3 x 14 doubles).
-template <int KIND>
-SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double span, int n, double kla, double ec,
+// Classical RK4, n equal substeps of length h; autonomous inside a call (Kla and the inflow held).
+//   FLOW 0: closed reactor - reaction intervals in which this wave doses no carbon, idle phase (idle_dxdt :2424-2552)
+//   FLOW 1: carbon dosing - inflow Q = ec of concentration EC_conc in Ss, nothing else (reaction_dxdt :1757-1785)
+//   FLOW 2: filling - inflow Q = ld[0] of composition ld[1..13] (filling_dxdt :1555-1581)
+// Only the nine feedback components are carried through the stages (x, the running combination and one stage vector:
+// 3 x 9 doubles live).  The rest of the state has closed forms that RK4 reproduces to (Q h/V)^5 ~ 1e-38, i.e. exactly:
+//   V' = Q                      =>  V advances by h Q per substep; 1/V at the stage times is tracked by one Newton step
+//                                   (dosing moves V by 3e-8 of itself per substep) or taken afresh (filling),
+//   c' = (Q/V)(c_in - c)        =>  c(t1) = c0 + g (c_in - c0), g = (V1 - V0)/V1, for Si and Xi (no reaction), and for
+//   u = Salk - (Snh - Sno)/14       the charge balance u: the alkalinity row of the stoichiometry is (row Snh - row Sno)/14
+//                                   for every process (nu13_k = (nu10_k - nu9_k)/14 term by term, :1689-1725), so u only
+//                                   dilutes,
+//   Xp' = nu7 (rho4 + rho5) + (Q/V)(c_in - Xp): integrated with the others, but without a stage value when Q == 0.
+// With Q == 0 every flow term is an exact no-op (q = 0, g = 0), so a lane that doses nothing computes bit for bit the
+// same in the FLOW 1 code as in the FLOW 0 code: results do not depend on the wave-mates.
+template <int FLOW>
+SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, double kla, double Q,
                      const double (&ld)[SBR_NX]) {
-    const double h = span / (double)n;
-    const double h2 = 0.5 * h, h6 = h / 6.0, h3 = h / 3.0;
+    const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+    const double kla_sat = kla * p.So_sat;
+    double a[SBR_NA], xp = x[7];
+    sbr_gather(x, a);
+    const double v0 = x[0], n0 = x[10] - x[9];                 // V and Snh - Sno at the start
+    double v = v0, rv = FLOW ? sbr_rcp(v0) : 0.0;
     for (int s = 0; s < n; ++s) {
-        double k[SBR_NX], y[SBR_NX], acc[SBR_NX];
-        sbr_rhs<KIND>(p, x, kla, ec, ld, k);
+        double k[SBR_NA], y[SBR_NA], acc[SBR_NA], k7, y7 = xp, acc7, q = 0.0;
+        SbrRho o;
+        // what the inflow adds to the stage derivative of (w[], w7)
+        auto flow = [&](const double (&w)[SBR_NA], double w7) {
+            if (FLOW == 1) {
 #pragma unroll
-        for (int i = 0; i < SBR_NX; ++i) { acc[i] = x[i] + h6 * k[i]; y[i] = x[i] + h2 * k[i]; }
-        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+                for (int i = 0; i < SBR_NA; ++i) k[i] = __builtin_fma(q, i == A_SS ? (p.EC_conc - w[i]) : -w[i], k[i]);
+                k7 = __builtin_fma(-q, w7, k7);
+            } else if (FLOW == 2) {
+                k[A_SS] = __builtin_fma(q, ld[2] - w[A_SS], k[A_SS]); k[A_XS] = __builtin_fma(q, ld[4] - w[A_XS], k[A_XS]);
+                k[A_XBH] = __builtin_fma(q, ld[5] - w[A_XBH], k[A_XBH]); k[A_XBA] = __builtin_fma(q, ld[6] - w[A_XBA], k[A_XBA]);
+                k[A_SO] = __builtin_fma(q, ld[8] - w[A_SO], k[A_SO]); k[A_SNO] = __builtin_fma(q, ld[9] - w[A_SNO], k[A_SNO]);
+                k[A_SNH] = __builtin_fma(q, ld[10] - w[A_SNH], k[A_SNH]); k[A_SND] = __builtin_fma(q, ld[11] - w[A_SND], k[A_SND]);
+                k[A_XND] = __builtin_fma(q, ld[12] - w[A_XND], k[A_XND]);
+                k7 = __builtin_fma(q, ld[7] - w7, k7);
+            }
+        };
+        // stage 1 at (t, V)
+        sbr_rates(p, a, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
+        if (FLOW) { q = Q * rv; flow(a, xp); }
 #pragma unroll
-        for (int i = 0; i < SBR_NX; ++i) { acc[i] += h3 * k[i]; y[i] = x[i] + h2 * k[i]; }
-        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h6, k[i], a[i]); y[i] = __builtin_fma(h2, k[i], a[i]); }
+        acc7 = __builtin_fma(h6, k7, xp); if (FLOW) y7 = __builtin_fma(h2, k7, xp);
+        // stages 2 and 3 at (t + h/2, V + h/2 Q)
+        if (FLOW) {
+            const double vm = __builtin_fma(h2, Q, v);
+            rv = FLOW == 1 ? sbr_rcp_refine(vm, rv) : sbr_rcp(vm);
+            q = Q * rv;
+        }
+        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
+        if (FLOW) flow(y, y7);
 #pragma unroll
-        for (int i = 0; i < SBR_NX; ++i) { acc[i] += h3 * k[i]; y[i] = x[i] + h * k[i]; }
-        sbr_rhs<KIND>(p, y, kla, ec, ld, k);
+        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h3, k[i], acc[i]); y[i] = __builtin_fma(h2, k[i], a[i]); }
+        acc7 = __builtin_fma(h3, k7, acc7); if (FLOW) y7 = __builtin_fma(h2, k7, xp);
+        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
+        if (FLOW) flow(y, y7);
 #pragma unroll
-        for (int i = 0; i < SBR_NX; ++i) x[i] = acc[i] + h6 * k[i];
+        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h3, k[i], acc[i]); y[i] = __builtin_fma(h, k[i], a[i]); }
+        acc7 = __builtin_fma(h3, k7, acc7); if (FLOW) y7 = __builtin_fma(h, k7, xp);
+        // stage 4 at (t + h, V + h Q)
+        if (FLOW) {
+            v = __builtin_fma(h, Q, v);
+            rv = FLOW == 1 ? sbr_rcp_refine(v, rv) : sbr_rcp(v);
+            q = Q * rv;
+        }
+        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
+        if (FLOW) flow(y, y7);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(h6, k[i], acc[i]);
+        xp = __builtin_fma(h6, k7, acc7);
     }
+    sbr_scatter(a, x);
+    x[7] = xp;
+    // the components outside the stages
+    const double c14 = 1.0 / 14.0;
+    double u = __builtin_fma(-n0, c14, x[13]);                 // Salk - (Snh - Sno)/14 at the start
+    if (FLOW) {
+        const double g = (v - v0) * rv;                        // share of the final volume that flowed in; 0 if Q == 0
+        const double si_in = FLOW == 2 ? ld[1] : 0.0, xi_in = FLOW == 2 ? ld[3] : 0.0;
+        const double u_in = FLOW == 2 ? __builtin_fma(-(ld[10] - ld[9]), c14, ld[13]) : 0.0;
+        x[0] = v;
+        x[1] = __builtin_fma(g, si_in - x[1], x[1]);
+        x[3] = __builtin_fma(g, xi_in - x[3], x[3]);
+        u = __builtin_fma(g, u_in - u, u);
+    }
+    x[13] = __builtin_fma(x[10] - x[9], c14, u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -235,7 +291,10 @@ struct SbrCtl {
     int st_new;               // SBR_ST_* bits raised by this call
     double span;              // t_range[-1] - t_range[0] of the last interval
     int rows;                 // len(t_range) of the last interval: 9 or 10
+    double e_ec, dcv_ec;      // e_EC[-1], dcv_EC[-1] of the last interval (:1918-1921): only the trajectory export reads them
 };
+// the diagnostics sbr_reward appends to its four lists (module_reward_EQIOCI.py:109-112), before normalisation
+struct SbrRewardParts { double eqi2, ae, ec; };
 
 // the six components whose change over the (last) interval the observation reports (:1069-1076)
 #define SBR_NXD 6
@@ -287,30 +346,43 @@ template <typename X6>
 SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& xs6, bool aerobic) {
     const double t0 = c.t, t1 = t0 + p.t_delta;
     const double span = t1 - t0;
-    c.rows = (int)(span / p.dt);              // 9 or 10: fp rounding of (t+t_delta)-t   (:1339, :1384)
-    c.rows = c.rows < 2 ? 2 : (c.rows > SBR_KLA_HIST ? SBR_KLA_HIST : c.rows);   // bounded even if t was injected as garbage
+    // len(t_range) = int(span/dt): 9 or 10 with the fp rounding of (t+t_delta)-t (:1339, :1384).  Exact for every span:
+    // the two thresholds decide the values a valid t can produce, anything else takes the IEEE division.
+    if (span >= p.rows10_min) c.rows = 10;             // min(int(span/dt), SBR_KLA_HIST): the quotient is monotonic in span
+    else if (span >= p.rows9_min) c.rows = 9;
+    else {
+        c.rows = (int)(span / p.dt);
+        c.rows = c.rows < 2 ? 2 : (c.rows > SBR_KLA_HIST ? SBR_KLA_HIST : c.rows);   // bounded even if t was injected as garbage
+    }
+    const bool deriv = (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0);            // wave-uniform; tauD = 0 in the reference (:85, :94)
     // DO-PID -> Kla (velocity form: bias is the previous Kla).  In anoxic intervals the output is forced to 0
     // but the integral keeps winding with set-point 0 (:1974-1997).
     const double e = (aerobic ? c.u_do : 0.0) - c.so_m1;
-    const double dcv = (c.so_m1 - c.so_m2) / p.dt;
-    c.ie_do = c.ie_do + e * p.dt;
-    double kla = aerobic ? (p.Kc_DO * e + p.KcI_DO * c.ie_do + p.KcD_DO * dcv + c.kla_last) : 0.0;
-    if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - e * p.dt; }
-    if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - e * p.dt; }
+    const double edt = e * p.dt;
+    c.ie_do = c.ie_do + edt;
+    double kla = __builtin_fma(p.Kc_DO, e, p.KcI_DO * c.ie_do);
+    if (deriv) kla = kla + p.KcD_DO * ((c.so_m1 - c.so_m2) * p.inv_dt);
+    kla = aerobic ? kla + c.kla_last : 0.0;
+    if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - edt; }
+    if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - edt; }
     // NO3-PID -> EC (error sign reversed, :2006); forced to 0 in aerobic intervals while its integral winds (:1918-1937)
     const double e2 = c.sno_m1 - c.u_ec;
-    const double dcv2 = (c.sno_m1 - c.sno_m2) / p.dt;
-    c.ie_ec = c.ie_ec + e2 * p.dt;
-    double ec = aerobic ? 0.0 : (p.Kc_EC * e2 + p.KcI_EC * c.ie_ec + p.KcD_EC * dcv2 + c.ec_last);
-    if (ec < p.EC_min) { ec = p.EC_min; c.ie_ec = c.ie_ec - e2 * p.dt; }
-    else if (ec > p.EC_max) { ec = p.EC_max; c.ie_ec = c.ie_ec - e2 * p.dt; }
+    const double e2dt = e2 * p.dt;
+    c.e_ec = e2; c.dcv_ec = (c.sno_m1 - c.sno_m2) * p.inv_dt;
+    c.ie_ec = c.ie_ec + e2dt;
+    double ec = __builtin_fma(p.Kc_EC, e2, p.KcI_EC * c.ie_ec);
+    if (deriv) ec = ec + p.KcD_EC * ((c.sno_m1 - c.sno_m2) * p.inv_dt);
+    ec = aerobic ? 0.0 : ec + c.ec_last;
+    if (ec < p.EC_min) { ec = p.EC_min; c.ie_ec = c.ie_ec - e2dt; }
+    else if (ec > p.EC_max) { ec = p.EC_max; c.ie_ec = c.ie_ec - e2dt; }
     xs6.put(x);
-    // wave-uniform choice: if no lane doses, V/Si/Xi are constants of the interval
+    // wave-uniform choice of the code path only: a lane with ec == 0 computes the same bits in either (sbr_rk4)
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<3>(p, x, span, p.substeps, kla, 0.0, nold);
-    else sbr_rk4<0>(p, x, span, p.substeps, kla, ec, nold);
+    const double h = span * p.inv_substeps;
+    if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<0>(p, x, h, p.substeps, kla, 0.0, nold);
+    else sbr_rk4<1>(p, x, h, p.substeps, kla, ec, nold);
     if (c.n_new == 0) c.knew[0] = kla; else c.knew[1] = kla;      // n_new <= 2, see SbrCtl
     c.n_new += 1;
     c.kla_last = kla;
@@ -359,34 +431,35 @@ SBR_DEV void sbr_hist_apply(const SbrCtl& c, double (&hist)[SBR_KLA_HIST]) {
 // module_reward_EQIOCI.py:4-115.  Kla got one append per interval, EC got rows-1:  Kla[-rows:-1] is
 // the rows-1 values BEFORE the current one, EC[-rows:-1] = last value of the previous interval +
 // (rows-2) x current.
-SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], const double (&x)[SBR_NX]) {
+SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], const double (&x)[SBR_NX],
+                          SbrRewardParts& rp) {
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
-    const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
-    const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
-    const double bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * (xbh + xba));
-    const double cod = x[2] + x[1] + xs + xi + xbh + xba + xp;
-    const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
-    const double eqi2 = eqi / 10;
+    const double bio = xbh + xba, part = (xs + xi) + (bio + xp);
+    const double snkj = x[10] + x[11] + x[12] + 0.08 * bio + 0.06 * (xp + xi);
+    const double bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * bio);
+    const double cod = x[2] + x[1] + part;
+    // EQI :40-47 with SS = 0.75 part; EQI2 = EQI/10 (:60); the constant divisors are folded (<= 1 ulp each)
+    const double eqi2 = (1.5 * part + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (0.66 / 1000 / 10);
     const double td = 0.002 / 24;
     double ksum = (c.rows >= 10) ? hist[0] : 0.0;          // 9 previous values if rows == 10, else 8
 #pragma unroll
     for (int j = 1; j < SBR_KLA_HIST - 1; ++j) ksum = ksum + hist[j];
-    const double ae = 8 / (c.span * 1.8 * 1000) * (1.32 * ksum * td);
-    double esum = c.ec_prev;
-    for (int j = 0; j < c.rows - 2; ++j) esum = esum + c.ec_last;
-    const double ec_oci = p.EC_conc * esum * td / (c.span * 1000);
-    const double oci = ae + ec_oci;
-    return (1 - (eqi2 * eqi2 + oci * oci)) / 473;
+    // AE_OCI = 8/((t1-t0) 1800) 1.32 sum(Kla) td (:70-71), EC_OCI = EC_conc sum(EC) td/((t1-t0) 1000) (:79): one reciprocal
+    const double esum = __builtin_fma((double)(c.rows - 2), c.ec_last, c.ec_prev);
+    const double aek = (8 * 1.32 * td / 1800) * ksum, eck = (p.EC_conc * td / 1000) * esum, rs = sbr_rcp(c.span);
+    const double oci = (aek + eck) * rs;
+    rp.eqi2 = eqi2; rp.ae = aek * rs; rp.ec = eck * rs;        // dead code unless the trajectory export is on
+    return (1 - __builtin_fma(eqi2, eqi2, oci * oci)) * (1.0 / 473);
 }
 
 // module_reward_continuous_G2ANET.py:4-45 (cfg.reward_kind = 1): piecewise-linear in Ss, So, Sno, Snh of the end state
 SBR_DEV double sbr_reward_g2anet(const double (&x)[SBR_NX]) {
     const double ss = x[2], so = x[8], sno = x[9], snh = x[10];
-    const double r_ec = ss < 0 ? 1.0 : -(ss - 0) / (10 - 0) + 1;
+    const double r_ec = ss < 0 ? 1.0 : -(ss - 0) * (1.0 / (10 - 0)) + 1;
     const double r_e = so < 1.5 ? 0.0 : -(1 / (8 - 1.5)) * (so - 8) + 0;
-    const double r_sno = sno < 4 ? 1.0 : -(sno - 4) / (20 - 4) + 1;
-    const double r_snh = snh < 4 ? 1.0 : -(snh - 4) / (20 - 4) + 1;
-    return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) / 10;
+    const double r_sno = sno < 4 ? 1.0 : -(sno - 4) * (1.0 / (20 - 4)) + 1;
+    const double r_snh = snh < 4 ? 1.0 : -(snh - 4) * (1.0 / (20 - 4)) + 1;
+    return (1 * r_ec + 1.5 * r_e + 2 * r_sno + 2 * r_snh) * (1.0 / 10);
 }
 
 // module_reward_continuous.py:4-65 (cfg.reward_kind = 2, the reward of SbrEnv3/SbrEnv4): operating cost only.
@@ -508,7 +581,7 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    sbr_rk4<2>(p, x, span, n, kla, 0.0, nold);
+    sbr_rk4<0>(p, x, span / (double)(n > 0 ? n : 1), n, kla, 0.0, nold);
     sbr_hist_push(hist, kla);                         // Kla.append in Sim_idle (:2578)
     c.kla_last = kla;
     return qw;
@@ -520,15 +593,16 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
 // compile-time variant, so that the default kernels carry none of it.
 template <bool OCI>
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX],
-                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum) {
+                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp) {
     sbr_hist_apply(c, hist);
     double r;
+    rp.eqi2 = 0.0; rp.ae = 0.0; rp.ec = 0.0;
     if (OCI) {
         ksum = ksum + c.knew[0];
         if (c.n_new > 1) ksum = ksum + c.knew[1];
         r = sbr_reward_oci(p, 1, c.kla_last, 0.0, 0.0, 0.0);
     } else {
-        r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x);     // wave-uniform choice
+        r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x, rp);     // wave-uniform choice
     }
     t_obs = c.t;
     dn = false;
@@ -568,12 +642,12 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], double t_st
         const double g1 = (i + 1 == n2 - 1) ? t_end : (double)(i + 1) * step + t_start;
         const double e = sp - so;
         double dcv = 0.0;
-        if (i >= 1) { dcv = (so - so_prev) / p.cyc_dt; ie = ie + e * p.cyc_dt; }
+        if (i >= 1) { dcv = (so - so_prev) * p.inv_cyc_dt; ie = ie + e * p.cyc_dt; }
         k = p.cyc_Kc * e + p.cyc_KcI * ie + p.cyc_KcD * dcv + bias;
         if (k > p.Kla_max) { k = p.Kla_max; ie = ie - e * p.cyc_dt; }
         if (k < p.Kla_min) { k = p.Kla_min; ie = ie - e * p.cyc_dt; }
         if (i == 0) bias = k;
-        sbr_rk4<FILL ? 1 : 2>(p, x, g1 - g0, p.substeps, k, 0.0, ld);
+        sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
         sum = sum + k;
         so_prev = so; so = x[8];
     }

@@ -111,6 +111,11 @@ typedef struct sbr_config {
                                   episode, pumping of Qw and Qeff, -246 if the effluent ammonia is >= 4 g/m3) */
     int32_t act_f64;           /* 0: sbr_step reads float32 actions; 1: float64.  A finished env ignores step()
                                   until sbr_reset either way (the reference leaves resetting to the caller) */
+    int32_t random_scenario;   /* what sbr_reset / sbr_cycle_reset do when `scenario` is NULL: 0 = the fixed scenario of the
+                                  reference class (6 for SbrOS :180, 0 for SbrEnv2 :104); 1 = draw one of the 8 scenarios
+                                  per env and reset on the device, uniformly, as SbrEnv4.reset does with
+                                  np.random.choice(8, 1) (gym_SBR_env4.py:107): Philox4x32-10 keyed by `seed`, stream 2,
+                                  subsequence = GLOBAL env id (sbr_draw_scenarios returns the same draw) */
 } sbr_config;
 
 typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for N envs on one GPU */
@@ -156,9 +161,13 @@ int sbr_reset_carry(sbr_env* env, uint64_t seed, const int32_t* scenario, const 
 /* trajectory export (replaces the growing lists of SbrOS.trajectory(), gym_SBR_oneshot.py:1275-1288): while a trace
  * buffer is set, every sbr_step call appends one record for each of the first n_envs environments at index = calls since
  * reset (records beyond capacity are dropped).  buf is [capacity][SBR_NTRACE][n_envs] float64, DEVICE pointer, owned by
- * the caller; buf = NULL switches tracing off.  Record: t, x[14] (end of the call), Kla, EC (of the last interval),
- * reward, done. */
-#define SBR_NTRACE 19
+ * the caller; buf = NULL switches tracing off.  Record (SBR_TR_*): t, x[14] (end of the call), Kla, EC (of the call's last
+ * interval), reward, done, the clipped set-points u_DO / u_EC in force (:862-870, :898-906), the NO3-PID's e_EC, ie_EC,
+ * dcv_EC (:1918-1926, :2006-2014) and the four diagnostics sbr_reward appends (module_reward_EQIOCI.py:109-112):
+ * EQI2, OCI2 = AE_OCI2 + EC_OCI2, AE_OCI2, EC_OCI2. */
+#define SBR_NTRACE 28
+enum { SBR_TR_T = 0, SBR_TR_X0 = 1, SBR_TR_KLA = 15, SBR_TR_EC, SBR_TR_REWARD, SBR_TR_DONE, SBR_TR_U_DO, SBR_TR_U_EC,
+       SBR_TR_E_EC, SBR_TR_IE_EC, SBR_TR_DCV_EC, SBR_TR_R_EQI, SBR_TR_R_OCI, SBR_TR_R_AE, SBR_TR_R_EC };
 int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity);
 
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
@@ -218,6 +227,10 @@ int sbr_eval_rhs(sbr_env* env, int32_t kind, int64_t n, const double* x, const d
 
 /* device-side normal draws used by sbr_reset when rnd == NULL, exposed for tests: out [N][48]. */
 int sbr_draw_normals(sbr_env* env, uint64_t seed, double* out, void* stream);
+
+/* the scenario each env gets from sbr_reset(seed, scenario = NULL) when cfg.random_scenario = 1: out [N] int32, DEVICE
+ * pointer (replaces np.random.choice(8, 1), gym_SBR_env4.py:107). */
+int sbr_draw_scenarios(sbr_env* env, uint64_t seed, int32_t* out, void* stream);
 
 /* timing helper for bench.py: average device time (ms) per sbr_step launch between two marks,
  * measured with HIP events on `stream` (the stream the kernels are launched on). */

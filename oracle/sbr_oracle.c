@@ -33,7 +33,7 @@ typedef struct {
     double t_ratio[8];
     double cyc_Kc, cyc_tauI, cyc_tauD, cyc_dt;
     double x0[NX];
-    int32_t substeps, out_f64, terminal, reward_kind, act_f64;
+    int32_t substeps, out_f64, terminal, reward_kind, act_f64, random_scenario;
 } sbro_params;
 
 /* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
@@ -84,7 +84,7 @@ void sbro_default_params(sbro_params* p) {
                                   13.3791460027604, 0.00562880208518134, 0.35996687629947, 1.86916737961228,
                                   3.790463057094611};
     memcpy(p->x0, x0, sizeof x0);
-    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->reward_kind = 0; p->act_f64 = 0;
+    p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->reward_kind = 0; p->act_f64 = 0; p->random_scenario = 0;
 }
 
 int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }
@@ -239,6 +239,14 @@ void sbro_policy_action(const sbro_params* p, uint64_t seed, uint64_t env_id, ui
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     a[0] = (float)(u53(c[0], c[1]) * p->act_DO_max);
     a[1] = (float)(u53(c[2], c[3]) * p->act_EC_max);
+}
+
+/* scenario of one env for a reset with cfg.random_scenario = 1 (stream 2): uniform over the 8 influent scenarios, the
+ * restatement of np.random.choice(8, 1) at gym_SBR_env4.py:107 with the product's counter-based generator */
+int32_t sbro_scenario_draw(uint64_t seed, uint64_t env_id) {
+    uint32_t c[4] = {0u, 2u, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (int32_t)(c[0] & 7u);
 }
 
 /* ---------------------------------------------------------------------------------- observations */
@@ -412,6 +420,29 @@ static double reward_of(const sbro_params* p, const sbro_env* e) {
     const double ec_oci = p->EC_conc * esum * td / (e->span * 1000);
     const double oci = ae + ec_oci;
     return (1 - (eqi2 * eqi2 + oci * oci)) / 473;
+}
+
+/* the four diagnostics module_reward_EQIOCI.py:109-112 appends per call: EQI2 (:60), OCI2 = AE_OCI2 + EC_OCI2 (:101),
+ * AE_OCI2 = AE_OCI/AE_OCI_max (:72-73), EC_OCI2 = EC_OCI/EC_OCI_max (:80-81); evaluated on the env as sbro_step left it */
+void sbro_reward_parts(const sbro_params* p, const sbro_env* e, double* out4) {
+    const double* x = e->x;
+    const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
+    const double snkj = x[10] + x[11] + x[12] + 0.08 * (xbh + xba) + 0.06 * (xp + xi);
+    const double ss_ = 0.75 * (xs + xi + xbh + xba + xp);
+    const double bod5 = 0.25 * (x[2] + xs + (1 - 0.08) * (xbh + xba));
+    const double cod = x[2] + x[1] + xs + xi + xbh + xba + xp;
+    const double eqi = (2 * ss_ + 1 * cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
+    const double td = 0.002 / 24, so_sat = 8;
+    const int n = e->n_rows;
+    double ksum = 0;
+    for (int j = KLA_HIST - n; j < KLA_HIST - 1; ++j) ksum = ksum + e->kla_hist[j];
+    const double ae = so_sat / (e->span * 1.8 * 1000) * (1.32 * ksum * td);
+    const double ae_max = 1.32 * (240 * 11) * td * (so_sat / ((td * 11) * 1.8 * 1000));
+    double esum = 0 + e->ec_prev;
+    for (int j = 0; j < n - 2; ++j) esum = esum + e->ec_last;
+    const double ec_oci = p->EC_conc * esum * td / (e->span * 1000);
+    const double ec_max = p->EC_conc * (0.0005 * 11) * td / ((td * 11) * 1000);
+    out4[0] = eqi / 10; out4[2] = ae / ae_max; out4[3] = ec_oci / ec_max; out4[1] = out4[2] + out4[3];
 }
 
 /* ---------------------------------------------------------------------------------- terminal */

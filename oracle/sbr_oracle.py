@@ -22,7 +22,7 @@ class Params(C.Structure):
         ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32)]
+        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32)]
 
 
 class Env(C.Structure):
@@ -133,6 +133,20 @@ class OracleBatch:
         out = np.empty((self.n, 48))
         for i in range(self.n):
             lib().sbro_draw_normals(C.c_uint64(seed), C.c_uint64(self.first_env_id + i), _p(out[i]))
+        return out
+
+    def scenarios(self, seed):
+        """The scenario each env draws at a reset with cfg.random_scenario = 1 (np.random.choice(8, 1), gym_SBR_env4.py:107)."""
+        f = lib().sbro_scenario_draw
+        f.restype = C.c_int32
+        return np.array([f(C.c_uint64(seed), C.c_uint64(self.first_env_id + i)) for i in range(self.n)], dtype=np.int32)
+
+    def reward_parts(self):
+        """[n][4]: EQI2, OCI2, AE_OCI2, EC_OCI2 of the call just made (module_reward_EQIOCI.py:109-112)."""
+        out = np.empty((self.n, 4))
+        envs = self._envp()
+        for i in range(self.n):
+            lib().sbro_reward_parts(C.byref(self.p), C.byref(envs[i]), _p(out[i]))
         return out
 
     def load_state(self, x, ctrl):
