@@ -14,7 +14,11 @@ _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 from . import _capi  # noqa: F401,E402
 from .registration import make, register_with_gym, registered_ids  # noqa: F401,E402
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+# The reference registers its ids when `gym_SBR` is imported (gym_SBR/__init__.py:3-12); so does this package, with
+# whichever of gymnasium / gym is installed (neither is in this image: then only gym_sbr2_amd.make() knows the ids).
+REGISTERED_WITH = register_with_gym()
 
 
 def __getattr__(name):          # torch is imported only when the env classes are asked for

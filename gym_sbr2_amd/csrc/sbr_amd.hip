@@ -308,44 +308,77 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // Values that only have to SURVIVE the integration (nine Kla history values, return, packed steps/status/done, the six
 // xdot start values: 17 doubles per lane, 18 with the operating-cost reward's running sum) are parked in LDS, not in
 // VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and the RK4 loop keeps its registers
-// (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l is at park[j*SBR_BLOCK + l] (conflict-free).
-// The Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally wave-uniform
-// (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the per-lane form.
-#define SBR_NPARK (SBR_KLA_HIST - 1 + 2 + SBR_NXD)
+// (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at park[(w*NSLOT + j)*64 + l] (conflict-free).
+#define SBR_NPARK (SBR_KLA_HIST + 2 + SBR_NXD)
+
+// One output row per lane (obs: 18 values, state: 15) -> the caller's row-major tensor.  A full wavefront owns 64
+// consecutive rows, i.e. ONE contiguous block of 64 x NV x sizeof(OutT) bytes (4608 B of float32 observations): the rows go
+// through the wave's own LDS region and leave as 16-byte-per-lane stores (obs + state: 9 store instructions per lane).
+// Written directly, every lane stores NV separate dwords at a 72- or 60-byte stride: 33 store instructions, each touching
+// 36 cache lines; with all 1024 waves in their epilogue at once those stores queue behind each other (measured with the
+// stamp build: 2.8 us of a 17.6 us launch).  Waves that are not full (last wave of a ragged batch) and misaligned
+// destinations take the direct form.  LDS operations of one wave execute in issue order, so the region can be reused
+// without a workgroup barrier; the wave barrier keeps the compiler from reordering across it.
+template <typename OutT, int NV>
+SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the workgroup */, uint32_t l, char* stage,
+                        bool wide, const OutT (&v)[NV]) {
+    constexpr int RB = NV * (int)sizeof(OutT);                 // bytes per row
+    constexpr int CH = 64 * RB / 16;                           // 16-byte chunks per wave
+    const uint32_t lane = l & 63u;
+    char* wdst = reinterpret_cast<char*>(rows + (size_t)(l & ~63u) * NV);
+    if (wide && (reinterpret_cast<uintptr_t>(wdst) & 15u) == 0) {
+        OutT* mine = reinterpret_cast<OutT*>(stage + lane * RB);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) mine[k] = v[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r * 64 < CH; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CH || c < CH)
+                *reinterpret_cast<uint4*>(wdst + c * 16) = *reinterpret_cast<const uint4*>(stage + c * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) rows[(size_t)l * NV + k] = v[k];
+    }
+}
+
 template <typename OutT, typename ActT, int W, bool OCI>
 __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
                                                       OutT* __restrict__ obs, OutT* __restrict__ state,
                                                       OutT* __restrict__ reward, uint8_t* __restrict__ done) {
-    __shared__ double park[(SBR_NPARK + (OCI ? 1 : 0)) * SBR_BLOCK];
+    // wave-major: wave w owns park[w][slot][64], 18 (19) slots x 512 B = 9216 B, which is also what 64 float64 observation
+    // rows take when the region is reused for the output transpose
+    constexpr int NSLOT = SBR_NPARK + (OCI ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) double park[NSLOT * SBR_BLOCK];
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK;
     if (i0 + l >= b.n) return;
-    double* my = park + l;                    // slot j of this lane: my[j * SBR_BLOCK]
+    double* wave_lds = park + (l >> 6) * (NSLOT * 64);
+    double* my = wave_lds + (l & 63u);        // slot j of this lane: my[j * 64]
     double x[SBR_NX];
     SbrCtl c;
     SBR_STAMP(0, false);
+    // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
+    // in logical order, whose rows depend on t: a second, dependent round trip)
     load_x(b, i0, l, x);
     load_ctl_pre(b, i0, l, (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0) || b.trace != nullptr, c);
-    const int kb = ring_k(p, c.t) % SBR_KLA_HIST;          // ring position of the oldest entry (= slot the next Kla goes to)
-    const int kb_u = __builtin_amdgcn_readfirstlane(kb);
-    const bool ring_uniform = __builtin_amdgcn_ballot_w64(kb != kb_u) == 0ull;
     const double meta0 = CTRL(R_META);
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
-    if (ring_uniform) {
-        c.kla_last = CTRL(R_RING0 + ring_wrap(kb_u + SBR_KLA_HIST - 1));
 #pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_wrap(kb_u + j));
-    } else {
-        c.kla_last = CTRL(R_RING0 + ring_wrap(kb + SBR_KLA_HIST - 1));
-#pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) my[j * SBR_BLOCK] = CTRL(R_RING0 + ring_wrap(kb + j));
-    }
-    const double kla_before = c.kla_last;
-    my[9 * SBR_BLOCK] = CTRL(R_RET); my[10 * SBR_BLOCK] = meta0;
-    SbrX6Lds x6{my + 11 * SBR_BLOCK};
-    if (OCI) my[SBR_NPARK * SBR_BLOCK] = CTRL(R_KSUM);    // only this reward keeps the running sum of Kla
+    for (int j = 0; j < SBR_KLA_HIST; ++j) my[j * 64] = CTRL(R_RING0 + j);       // physical slot order
+    my[10 * 64] = CTRL(R_RET); my[11 * 64] = meta0;
+    SbrX6Lds x6{my + 12 * 64};
+    if (OCI) my[SBR_NPARK * 64] = CTRL(R_KSUM);           // only this reward keeps the running sum of Kla
     x6.put(x);
+    const int kb = ring_k(p, c.t) % SBR_KLA_HIST;          // slot of the oldest entry = where the next Kla goes
+    c.kla_last = my[ring_wrap(kb + SBR_KLA_HIST - 1) * 64];
+    const double kla_before = c.kla_last;
     SBR_STAMP(1, true);                       // every load has returned, the parked values are in LDS
     double t_obs = p.t_cycle, r = 0.0;
     bool dn = true;
@@ -359,10 +392,10 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
         sbr_run_intervals(p, c, x, a0, a1, x6);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
 #pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[j * SBR_BLOCK];
+        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[ring_wrap(kb + j) * 64];      // logical order, oldest first
         hist[SBR_KLA_HIST - 1] = kla_before;
         x6.get(xa6);
-        double ksum = OCI ? my[SBR_NPARK * SBR_BLOCK] : 0.0;
+        double ksum = OCI ? my[SBR_NPARK * 64] : 0.0;
         r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum, rp);
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         if (OCI) CTRL(R_KSUM) = ksum;
@@ -376,6 +409,11 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) XROW(j) = x[j];
         }
         store_ctl(b, i0, l, c);
+        // the Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally
+        // wave-uniform (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the
+        // per-lane form
+        const int kb_u = __builtin_amdgcn_readfirstlane(kb);
+        const bool ring_uniform = __builtin_amdgcn_ballot_w64(kb != kb_u) == 0ull;
         if (dn && p.terminal) {           // the idle phase appended one more Kla: the logical history moved by n_new + 1
             store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
             CTRL(R_QW) = qw;
@@ -386,8 +424,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             CTRL(R_RING0 + kb) = c.knew[0];
             if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
         }
-        meta_unpack(my[10 * SBR_BLOCK], steps, status, was_done);
-        CTRL(R_RET) = my[9 * SBR_BLOCK] + r;
+        meta_unpack(my[11 * 64], steps, status, was_done);
+        CTRL(R_RET) = my[10 * 64] + r;
         CTRL(R_META) = meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn);
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
@@ -412,8 +450,18 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
     SBR_STAMP(5, false);                      // state stores issued
     if (reward) (reward + i0)[l] = (OutT)r;
     if (done) (done + i0)[l] = dn ? 1 : 0;
-    if (obs) sbr_write_obs<OutT>((obs + i0 * SBR_NOBS) + l * SBR_NOBS, 1, t_obs, x, xa6, x);
-    if (state) sbr_write_state<OutT>((state + i0 * SBR_NSTATE) + l * SBR_NSTATE, 1, t_obs, x);
+    const bool wide = __builtin_amdgcn_ballot_w64(true) == ~0ull;      // all 64 lanes of the wave hold an env
+    char* stage = reinterpret_cast<char*>(wave_lds);
+    if (obs) {
+        OutT o[SBR_NOBS];
+        sbr_write_obs<OutT>(o, 1, t_obs, x, xa6, x);
+        store_rows<OutT, SBR_NOBS>(obs + i0 * SBR_NOBS, l, stage, wide, o);
+    }
+    if (state) {
+        OutT sv[SBR_NSTATE];
+        sbr_write_state<OutT>(sv, 1, t_obs, x);
+        store_rows<OutT, SBR_NSTATE>(state + i0 * SBR_NSTATE, l, stage, wide, sv);
+    }
     SBR_STAMP(6, false);                      // output stores issued
     SBR_STAMP(7, true);                       // every store acknowledged
 }

@@ -313,15 +313,15 @@ struct SbrX6Reg {
 #ifndef SBR_BLOCK
 #define SBR_BLOCK 256
 #endif
-struct SbrX6Lds {          // slot j of lane l lives at base[j * SBR_BLOCK + l]: conflict-free, 8-byte accesses
+struct SbrX6Lds {          // slot j of the lane lives at base[j * 64] inside its wave's region: conflict-free, 8-byte accesses
     double* base;
     SBR_DEV void put(const double (&x)[SBR_NX]) {
-        base[0 * SBR_BLOCK] = x[2]; base[1 * SBR_BLOCK] = x[5]; base[2 * SBR_BLOCK] = x[6]; base[3 * SBR_BLOCK] = x[8]; base[4 * SBR_BLOCK] = x[9];
-        base[5 * SBR_BLOCK] = x[10];
+        base[0 * 64] = x[2]; base[1 * 64] = x[5]; base[2 * 64] = x[6]; base[3 * 64] = x[8]; base[4 * 64] = x[9];
+        base[5 * 64] = x[10];
     }
     SBR_DEV void get(double (&o)[SBR_NXD]) const {
 #pragma unroll
-        for (int j = 0; j < SBR_NXD; ++j) o[j] = base[j * SBR_BLOCK];
+        for (int j = 0; j < SBR_NXD; ++j) o[j] = base[j * 64];
     }
 };
 

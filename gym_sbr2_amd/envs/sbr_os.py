@@ -7,8 +7,8 @@ id `SBROS-v1`) with the same surface, backed by the batched HIP environment at N
 
 Outputs are float64 like the reference's.  Differences, all deliberate: state lives on the GPU
 instead of module globals (so several instances can coexist), the influent noise comes from an
-explicit `seed`/`rnd` instead of the global numpy RNG, and `trajectory()` returns what this
-build records (per-call rewards and states), not the reference's 18 growing lists.
+explicit `seed`/`rnd` instead of the global numpy RNG, and the 18 lists of `trajectory()` are
+sampled once per step() call (see its docstring).
 """
 import numpy as np
 import torch
@@ -88,15 +88,35 @@ class SbrOS:
             out.append(ok)
         return out
 
-    def trajectory(self):
-        """Per-call records of the running episode (the reference returns 18 growing lists sampled on LSODA's output
-        grid, :1275-1288; this build records the end of every call on the device): t_t, x_t [calls,14], Kla, EC,
-        reward_t, plus the normalised states returned by step()."""
+    def trajectory(self, as_dict=False):
+        """The reference's 18-tuple, in its order (gym_SBR_oneshot.py:1288):
+
+            t_t, x_t, u_DO_t, u_EC_t, state_t, So_t, Ss_t, EC, Sno_t, dcv_EC, ie_EC, e_EC,
+            reward_t, reward_EQI_t, reward_OCI_t, reward_AE_t, reward_EC_t, Snh_t
+
+        Every list has ONE entry per step() call of the running episode, recorded on the device at the end of the call
+        (for a call that runs two control intervals: of the second, like the reward).  The reference grows t_t, x_t, the
+        four concentration lists and the two set-point lists by the 8 or 9 rows of LSODA's output grid per interval, and its
+        controller lists (EC, dcv_EC, ie_EC, e_EC) also hold the entries of the fill phase; the fixed-step integrator has
+        no such grid, so those lists are sampled per call here.  reward_t and the four reward diagnostics
+        (module_reward_EQIOCI.py:109-112) are per call in the reference too.  state_t, which the reference leaves empty
+        (its append is commented out, :436), holds the state vector step() returned.
+        as_dict=True returns the same arrays by name (plus Kla, the DO controller's output)."""
+        from .. import _capi as K
         n = len(self._rewards)
-        rec = self._trace[:n, :, 0].cpu().numpy()
-        return {"t_t": rec[:, 0], "x_t": rec[:, 1:15], "Kla": rec[:, 15], "EC": rec[:, 16], "reward_t": rec[:, 17],
-                "So_t": rec[:, 9], "Ss_t": rec[:, 3], "Sno_t": rec[:, 10], "Snh_t": rec[:, 11],
-                "state_t": [s.copy() for s in self._states]}
+        rec = self._trace[:n].cpu().numpy()[:, :, 0]
+        x_t = rec[:, K.TR_X0:K.TR_X0 + 14]
+        cols = {"t_t": rec[:, K.TR_T], "x_t": x_t, "u_DO_t": rec[:, K.TR_U_DO], "u_EC_t": rec[:, K.TR_U_EC],
+                "state_t": [s.copy() for s in self._states], "So_t": x_t[:, 8], "Ss_t": x_t[:, 2], "EC": rec[:, K.TR_EC],
+                "Sno_t": x_t[:, 9], "dcv_EC": rec[:, K.TR_DCV_EC], "ie_EC": rec[:, K.TR_IE_EC], "e_EC": rec[:, K.TR_E_EC],
+                "reward_t": rec[:, K.TR_REWARD], "reward_EQI_t": rec[:, K.TR_R_EQI], "reward_OCI_t": rec[:, K.TR_R_OCI],
+                "reward_AE_t": rec[:, K.TR_R_AE], "reward_EC_t": rec[:, K.TR_R_EC], "Snh_t": x_t[:, 10]}
+        if as_dict:
+            cols["Kla"] = rec[:, K.TR_KLA]
+            return cols
+        order = ("t_t x_t u_DO_t u_EC_t state_t So_t Ss_t EC Sno_t dcv_EC ie_EC e_EC reward_t reward_EQI_t reward_OCI_t "
+                 "reward_AE_t reward_EC_t Snh_t").split()
+        return tuple(cols[k] if k in ("x_t", "state_t") else cols[k].tolist() for k in order)
 
     def render(self, mode="human"):
         return None

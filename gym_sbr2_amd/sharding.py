@@ -48,6 +48,19 @@ def gather_returns(local, n_global, group=None):
     return torch.cat(parts)
 
 
+def local_device(env=None, n_devices=None):
+    """The GPU this process should use when none is named: LOCAL_RANK (what torch.distributed.run exports for one process
+    per GPU), modulo the number of visible devices; without a launcher, torch's current device.  Every rank defaulting to
+    device 0 would put all shards on one GPU - correct results, no scaling."""
+    import os
+    env = os.environ if env is None else env
+    if n_devices is None:
+        n_devices = torch.cuda.device_count()
+    if "LOCAL_RANK" in env:
+        return int(env["LOCAL_RANK"]) % max(int(n_devices), 1)
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
 class ShardedSbrOS:
     """This rank's block of a global batch of SBROS-v1 envs (one process per GPU)."""
 
@@ -59,7 +72,8 @@ class ShardedSbrOS:
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.n_global, self.rank, self.world = int(n_global), rank, world
         self.start, self.stop = shard_range(n_global, rank, world)
-        self.env = SbrOSVec(self.stop - self.start, device=0 if device is None else device, first_env_id=self.start, **kw)
+        self.device = local_device() if device is None else device
+        self.env = SbrOSVec(self.stop - self.start, device=self.device, first_env_id=self.start, **kw)
 
     @property
     def global_ids(self):
@@ -73,6 +87,10 @@ class ShardedSbrOS:
 
     def rollout(self, n_steps, policy_seed=0):
         return self.env.rollout(n_steps, policy_seed)
+
+    def gather_episode_returns_async(self, out64=None, dtype=torch.float32):
+        """As gather_episode_returns, with a caller-owned float64 scratch row (no allocation on the launch stream)."""
+        return gather_returns(self.env.episode_returns(out=out64).to(dtype), self.n_global)
 
     def gather_episode_returns(self, dtype=torch.float32):
         """[n_global] episode returns on every rank: the single collective of the path."""

@@ -36,7 +36,7 @@ class SbrOSVec:
     """
 
     def __init__(self, num_envs, device=0, first_env_id=0, out_dtype=torch.float32, config=None, tables=None,
-                 action_dtype=torch.float32, reward=None):
+                 action_dtype=torch.float32, reward=None, random_scenario=None):
         if not torch.cuda.is_available():
             raise _capi.SbrError("SbrOSVec needs a HIP device (torch.cuda.is_available() is False); "
                                  "this package has no CPU fallback")
@@ -49,6 +49,8 @@ class SbrOSVec:
             if reward not in _capi.REWARD_KINDS:
                 raise ValueError("reward must be one of %s" % sorted(_capi.REWARD_KINDS))
             self.cfg.reward_kind = _capi.REWARD_KINDS[reward]
+        if random_scenario is not None:       # reset(scenario=None) draws one of the 8 scenarios per env (SbrEnv4, gym_SBR_env4.py:107)
+            self.cfg.random_scenario = 1 if random_scenario else 0
         if out_dtype not in (torch.float32, torch.float64):
             raise ValueError("out_dtype must be torch.float32 or torch.float64")
         self.out_dtype = out_dtype
@@ -176,8 +178,9 @@ class SbrOSVec:
         return (ret, acts) if return_actions else ret
 
     def enable_trace(self, n_envs=1, capacity=463):
-        """Trajectory export: every step() appends [t, x(14), Kla, EC, reward, done] for the first n_envs envs at index =
-        calls since reset.  Returns the buffer [capacity, 19, n_envs] float64 (NaN where nothing was written)."""
+        """Trajectory export: every step() appends one record (_capi.TR_*: t, x(14), Kla, EC, reward, done, the set-points in
+        force, the NO3-PID's e/ie/dcv and the four reward diagnostics) for the first n_envs envs at index = calls since
+        reset.  Returns the buffer [capacity, NTRACE, n_envs] float64 (NaN where nothing was written)."""
         self._trace = torch.full((int(capacity), _capi.NTRACE, int(n_envs)), float("nan"), dtype=torch.float64,
                                  device=self.device)
         _capi.check(self.lib.sbr_set_trace(self._h, _ptr(self._trace), int(n_envs), int(capacity)), self._h)
@@ -238,6 +241,12 @@ class SbrOSVec:
         _capi.check(self.lib.sbr_eval_rhs(self._h, int(kind), n, _ptr(x), _ptr(kla), _ptr(ec), _ptr(ld), _ptr(dx),
                                           self._stream()), self._h)
         return dx
+
+    def draw_scenarios(self, seed):
+        """The scenario every env draws at reset(seed, scenario=None) when the config has random_scenario = 1 ([N] int32)."""
+        out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.sbr_draw_scenarios(self._h, C.c_uint64(int(seed)), _ptr(out), self._stream()), self._h)
+        return out
 
     def draw_normals(self, seed):
         out = torch.empty((self.num_envs, _capi.NSAMP), dtype=torch.float64, device=self.device)

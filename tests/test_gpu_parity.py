@@ -18,7 +18,6 @@ pytestmark = pytest.mark.gpu
 from oracle import sbr_oracle as O  # noqa: E402  (the checker, never the thing under test)
 
 CLOSED_LOOP_OK = ["const_2_5", "random_a", "max", "det_influent"]
-REFERENCE_NOISE = {"random_b": 2.573, "zeros": 1.350}     # golden's own distance from a tight solve, see test_oracle_golden
 
 
 @pytest.fixture(scope="module")
@@ -133,7 +132,8 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
     assert np.abs(obs0 - oobs0).max() < 1e-11                            # measured 4.4e-15
     for i, e in enumerate(E):
         assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6
-    worst_gold = np.zeros(n)
+    T = [golden("sbros_%s_tight" % name) for name in EPISODES]      # the reference itself at odeint rtol = atol = 1e-12
+    worst_gold, worst_tight = np.zeros(n), np.zeros(n)
     for c in range(ncall):
         o, s, r, d = env.step(torch.from_numpy(acts[c]).cuda())
         oo, os_, orr, od = ora.step(acts[c])
@@ -151,6 +151,8 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
         assert np.abs(ctrl[_capi.C_KLA_HIST0:_capi.C_KLA_HIST0 + 10].T - ora.envs["kla_hist"]).max() < 1e-9
         if c < ncall - 1:
             worst_gold = np.maximum(worst_gold, [gate(x[i], E[i]["step_x_end"][c]).max() for i in range(n)])
+            worst_tight = np.maximum(worst_tight, [gate(x[i], T[i]["step_x_end"][c]).max() for i in range(n)])
+            assert np.abs(_np(r) - [t["step_reward"][c] for t in T]).max() < 5e-7       # rewards, all six episodes
             for i, e in enumerate(E):      # rewards / observations against the reference itself
                 if EPISODES[i] in CLOSED_LOOP_OK:
                     # reward = (1 - S)/473 with S = EQI2^2 + OCI^2 <= ~5: a 1e-5 state error gives <= 2e-5*S/473 ~ 2e-7
@@ -164,8 +166,14 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
             assert gate(x[i], e["term_x_after_idle"]).max() <= 1.0
             assert abs(ctrl[_capi.C_RETURN][i] / float(e["episode_return"]) - 1) < 1e-5
             assert abs(ctrl[_capi.C_QW][i] / float(e["term_Qw"]) - 1) < 1e-5
-        else:                              # the reference's own LSODA noise exceeds the gate here (Ss only); documented
-            assert abs(worst_gold[i] / REFERENCE_NOISE[name] - 1) < 0.02, (name, worst_gold[i])
+        else:                              # the reference's own default-tolerance LSODA noise exceeds the gate here (Ss only)
+            print("[info] %s: device vs reference at default odeint tolerance: %.3f of the gate" % (name, worst_gold[i]))
+        # the closed-loop bar on ALL six episodes: the reference itself at tight integrator tolerance
+        t = T[i]
+        assert worst_tight[i] <= 1.0, (name, worst_tight[i])                       # measured worst 0.51 (So, random_b)
+        assert gate(x[i], t["term_x_after_idle"]).max() <= 1.0
+        assert abs(ctrl[_capi.C_RETURN][i] / float(t["episode_return"]) - 1) < 1e-5
+        assert abs(ctrl[_capi.C_QW][i] / float(t["term_Qw"]) - 1) < 1e-5
         assert abs(ctrl[_capi.C_QW][i] / ora.envs["qw"][i] - 1) < 1e-11           # measured 7e-14
     # a finished env ignores further calls until reset
     _, _, r, d = env.step(torch.from_numpy(acts[0]).cuda())
@@ -844,12 +852,89 @@ def test_reference_shaped_single_env(G):
             assert abs(reward - e["step_reward"][k]) < 1e-5 * abs(e["step_reward"][k])
         total += reward; k += 1
     assert k == 463 and abs(total / float(e["episode_return"]) - 1) < 1e-5      # reference: -0.87896708834557
-    tr = env.trajectory()
-    assert tr["x_t"].shape == (463, 14) and np.array_equal(tr["t_t"], e["step_t"])
-    assert np.abs(tr["reward_t"] - e["step_reward"]).max() < 5e-7 and abs(tr["reward_t"].sum() - total) < 1e-12
+    # trajectory(): the reference's 18-tuple, in its order (:1288), one entry per call
+    (t_t, x_t, u_DO_t, u_EC_t, state_t, So_t, Ss_t, EC, Sno_t, dcv_EC, ie_EC, e_EC, reward_t, reward_EQI_t, reward_OCI_t,
+     reward_AE_t, reward_EC_t, Snh_t) = env.trajectory()
+    assert x_t.shape == (463, 14) and np.array_equal(t_t, e["step_t"]) and all(
+        isinstance(v, list) and len(v) == 463 for v in (t_t, u_DO_t, u_EC_t, state_t, So_t, Ss_t, EC, Sno_t, dcv_EC, ie_EC, e_EC,
+                                                        reward_t, reward_EQI_t, reward_OCI_t, reward_AE_t, reward_EC_t, Snh_t))
+    assert np.abs(np.array(reward_t) - e["step_reward"]).max() < 5e-7 and abs(sum(reward_t) - total) < 1e-12
+    # the four diagnostics module_reward_EQIOCI.py:109-112 appends per call, against the reference's own lists
+    assert np.abs(np.array(reward_EQI_t) - e["step_r_EQI2"]).max() < 5e-7 * max(1.0, np.abs(e["step_r_EQI2"]).max())
+    assert np.abs(np.array(reward_OCI_t) - e["step_r_OCI2"]).max() < 5e-7
+    assert np.abs(np.array(reward_AE_t) - e["step_r_AE2"]).max() < 5e-7
+    assert np.abs(np.array(reward_EC_t) - e["step_r_EC2"]).max() < 5e-7
+    assert gate(x_t[:462], e["step_x_end"][:462]).max() <= 1.0 and np.array_equal(np.array(So_t), x_t[:, 8])
+    # closed loop against the reference's default-tolerance run: the NO3-PID's integral sums (Sno - u_EC) dt, so it carries
+    # the gate-level (1e-5) differences of Sno (<= 466 x 3e-4 x dt ~ 1.2e-5; measured 4.2e-8); EC itself is saturated at a
+    # clamp on almost every call of this episode and equal there
+    assert np.abs(np.array(ie_EC) - e["step_ie_EC"]).max() < 1.2e-5
+    assert (np.abs(np.array(EC) - e["step_EC"]) < 1e-9).mean() > 0.95 and np.abs(np.array(EC) - e["step_EC"]).max() <= 5e-4
+    # set-points in force: u_EC = clip(action[1]) in the anoxic phases, u_DO = clip(action[0]) in the aerobic ones (:862-906)
+    aer = e["iv_kind"][np.searchsorted(e["iv_call"], np.arange(463), side="right") - 1] == 1
+    assert np.array_equal(np.array(u_DO_t), np.where(aer, 2.0, 0.0)) and np.array_equal(np.array(u_EC_t), np.where(aer, 0.0, 5.0))
+    assert np.abs(np.array(e_EC)[1:] - (e["step_Sno_m1"][:-1] - np.array(u_EC_t)[1:]))[:461].max() < 1e-6    # e_EC = Sno[-1] - u_EC
+    assert all(np.array_equal(a, b) for a, b in zip(state_t[:3], env._states[:3]))
+    d = env.trajectory(as_dict=True)
+    assert np.array_equal(d["reward_t"], np.array(reward_t)) and np.abs(d["Kla"] - e["step_Kla"]).max() < 1e-3
     assert [a.tolist() for a in env.get_available_actions([0.05, 12.0], 2, 3)] == [[0.0, 1.0, 1.0], [1.0, 1.0, 0.0]]
     obs2 = env.reset(rnd=e["rnd"], carry_over=True)          # second cycle from where the first one ended
     assert len(obs2[0]) == 9 and obs2[0] != obs[0]
     with pytest.raises(NotImplementedError):
         G.make("SBR-v4")
     env.close()
+
+
+@pytest.mark.gpu
+def test_random_scenario_is_drawn_on_the_device(G, tables):
+    """cfg.random_scenario = 1: reset(scenario=None) gives every env one of the 8 influent scenarios, uniformly, as
+    SbrEnv4.reset does with np.random.choice(8, 1) (gym_SBR_env4.py:107) - Philox stream 2 keyed by the seed of the reset
+    and the GLOBAL env id, so a shard draws what the whole batch would."""
+    means, stds = tables
+    n = 4096
+    env = G.SbrOSVec(n, out_dtype=torch.float64, random_scenario=True)
+    ora = O.OracleBatch(n)
+    for seed in (0, 17):
+        sc = _np(env.draw_scenarios(seed))
+        assert np.array_equal(sc, ora.scenarios(seed)) and sc.min() == 0 and sc.max() == 7
+        assert np.abs(np.bincount(sc, minlength=8) / n - 0.125).max() < 0.03          # uniform: 4 sigma is 0.021
+        env.reset(seed=seed)                                                          # scenario=None: drawn on the device
+        want = ora.mix(means, stds, sc, ora.normals(seed))
+        assert np.abs(_np(env.influent()).T[:, 1:] - want[:, 1:]).max() < 1e-11
+    assert not np.array_equal(_np(env.draw_scenarios(0)), _np(env.draw_scenarios(17)))
+    win = G.SbrOSVec(100, first_env_id=1000, out_dtype=torch.float64, random_scenario=True)    # a shard's window
+    assert np.array_equal(_np(win.draw_scenarios(17)), _np(env.draw_scenarios(17))[1000:1100])
+    win.reset(seed=17)
+    assert np.array_equal(_np(win.influent()), _np(env.influent())[:, 1000:1100])
+    fixed = G.SbrOSVec(64, out_dtype=torch.float64)                                   # default: scenario 6, as SbrOS (:180)
+    fixed.reset(seed=3)
+    assert np.abs(_np(fixed.influent()).T[:, 1:] - O.OracleBatch(64).mix(means, stds, [6] * 64, O.OracleBatch(64).normals(3))[:, 1:]).max() < 1e-11
+    env.close(); win.close(); fixed.close()
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_wave_mates_or_shard_boundaries(G, tables):
+    """An env's arithmetic is independent of which envs share its wavefront: the same global envs stepped (a) as one batch,
+    (b) as shards cut at a non-multiple of 64, (c) alone, give BIT-IDENTICAL float64 plant and controller state through the
+    anoxic phase (where some lanes dose carbon and others do not, i.e. both integrator code paths occur inside a wave),
+    a phase boundary and the aerobic phase.  (The first version folded 1/V into the batched reciprocal of the dosing path
+    only, so a non-dosing lane rounded differently next to a dosing wave-mate.)"""
+    n, cut, calls = 200, 77, 70
+    rs = np.random.RandomState(5)
+    acts = np.stack([np.column_stack([rs.uniform(0, 8, n), np.where(rs.rand(n) < 0.5, 0.0, rs.uniform(0, 15, n))]) for _ in range(calls)])
+    scen = (np.arange(n) % 8).astype(np.int32)
+
+    def run(lo, hi):
+        env = G.SbrOSVec(hi - lo, first_env_id=lo, out_dtype=torch.float64, action_dtype=torch.float64)
+        env.reset(seed=9, scenario=scen[lo:hi])
+        for c in range(calls):
+            env.step(torch.from_numpy(acts[c, lo:hi]).cuda())
+        x, ctrl = env.get_state()
+        out = (_np(x).copy(), _np(ctrl).copy())
+        env.close()
+        return out
+    xa, ca = run(0, n)
+    assert (ca[7] == 0).any() and (ca[7] != 0).any()          # EC[-1]: some lanes dosed on the last anoxic call, others did not
+    for lo, hi in ((0, cut), (cut, n), (130, 131)):
+        xs, cs = run(lo, hi)
+        assert np.array_equal(xs, xa[:, lo:hi]) and np.array_equal(cs, ca[:, lo:hi]), (lo, hi)

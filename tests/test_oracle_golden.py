@@ -10,11 +10,12 @@ What is asserted, and why it is worded this way (measured numbers in DESIGN.md, 
   episode, with the golden Kla/EC, the end state is inside the gate (|d| <= 1e-5|ref| + 1e-5 scale).
 * RK4 vs the reference, CLOSED loop (chained over the whole episode): inside the gate for four of
   the six episodes.  In `random_b` and `zeros` the golden trajectory ITSELF is 2.6x / 1.35x outside
-  the gate (in Ss only) relative to a tight-tolerance (1e-12) solve of the same closed loop: the
+  the gate (in Ss only) relative to the reference's OWN run at tight tolerance (1e-12): the
   reference's default LSODA tolerance (1.5e-8) is amplified by the NO3-PID -> carbon-dosing loop
   (dEC = 100 dSno, dSs ~ 3030 dEC per interval).  No integrator other than the bit-identical LSODA
-  can follow it there, so for those two the test asserts RK4 against the tight solve instead and
-  asserts the golden exceedance, so that it stays visible rather than being tolerated silently.
+  can follow it there.  The closed-loop bar is therefore asserted on ALL SIX episodes against
+  fixtures of the unmodified reference run with odeint forced to rtol = atol = 1e-12
+  (sbros_*_tight.npz); the default-tolerance exceedance is printed, not asserted.
 """
 import numpy as np
 import pytest
@@ -258,31 +259,39 @@ def test_rk4_closed_loop_inside_gate_of_reference(name, tables):
     assert abs(b.envs["qw"][0] / float(e["term_Qw"]) - 1) < 1e-5
 
 
-@pytest.mark.parametrize("name", CLOSED_LOOP_REFERENCE_NOISE)
-def test_rk4_closed_loop_where_reference_noise_exceeds_gate(name, tables, monkeypatch):
-    """See the module docstring: here the golden trajectory is not reproducible to 1e-5 by anything
-    but the identical LSODA run.  RK4 must be inside the gate of the tight solve; the golden
-    exceedance is asserted (not hidden), in Ss only."""
-    from scipy.integrate import odeint as _ode
-    e = golden("sbros_" + name)
+@pytest.mark.parametrize("name", EPISODES)
+def test_rk4_closed_loop_inside_gate_of_the_reference_at_tight_tolerance(name, tables):
+    """The closed-loop bar on ALL six episodes, against the reference itself: tests/golden/sbros_*_tight.npz are the six
+    episodes run by the unmodified reference with every odeint call forced to rtol = atol = 1e-12 (oracle/gen_golden.py
+    tight_episodes).  RK4 with 10 substeps stays inside the 1e-5 gate over the whole chained episode, terminal phases,
+    return and wastage included (measured worst: 0.51, So in random_b)."""
+    e = golden("sbros_%s_tight" % name)
+    xs, b = _c_episode(e, tables)
     n = int(e["n_calls"])
-    monkeypatch.setattr(R, "odeint", lambda f, x, g, args=(): _ode(f, x, g, args=args, rtol=1e-12, atol=1e-12))
-    tight_env = R.SbrOsRef(tables)
-    tight_env.reset(rnd=e["rnd"])
-    tight = []
-    for k in range(n):
-        tight_env.step(e["actions"][k])
-        tight.append(tight_env.x.copy())
-    tight = np.array(tight)
+    assert float(e["odeint_tol"]) == 1e-12 and n == 463
+    assert gate(xs[:n - 1], e["step_x_end"][:n - 1]).max() <= 1.0
+    assert gate(xs[n - 1], e["term_x_after_idle"]).max() <= 1.0
+    assert abs(b.envs["ret"][0] / float(e["episode_return"]) - 1) < 1e-5
+    assert abs(b.envs["qw"][0] / float(e["term_Qw"]) - 1) < 1e-5
+    assert np.array_equal(b.envs["t"], e["step_t"][-1:])             # same time recurrence, same phase switches
+
+
+@pytest.mark.parametrize("name", CLOSED_LOOP_REFERENCE_NOISE)
+def test_rk4_closed_loop_where_reference_noise_exceeds_gate(name, tables, capsys):
+    """Informational: on these two episodes the reference's DEFAULT-tolerance trajectory is itself outside the gate of its
+    own tight-tolerance run (in Ss only; LSODA's 1.5e-8 local error amplified by the NO3-PID -> dosing loop), so nothing
+    but the bit-identical LSODA run can follow it to 1e-5.  The bar is the test above; this one only keeps the numbers
+    visible and checks that the excess is confined to Ss."""
+    e, tight = golden("sbros_" + name), golden("sbros_%s_tight" % name)
+    n = int(e["n_calls"])
     xs, _ = _c_episode(e, tables)
-    assert gate(xs[:n - 1], tight[:n - 1]).max() <= 1.0              # RK4 follows the true closed loop
-    g_gold = gate(e["step_x_end"][:n - 1], tight[:n - 1])
+    g_gold = gate(e["step_x_end"][:n - 1], tight["step_x_end"][:n - 1])
     g_rk4 = gate(xs[:n - 1], e["step_x_end"][:n - 1])
-    assert 1.0 < g_gold.max() < 3.0                                   # the reference's own noise
-    assert g_gold.max(0).argmax() == 2 and g_rk4.max(0).argmax() == 2  # component Ss
+    with capsys.disabled():
+        print("\n[info] %s: reference(default tol) vs reference(1e-12): %.3f of the gate; RK4 vs reference(default tol): %.3f"
+              % (name, g_gold.max(), g_rk4.max()))
     others = [i for i in range(14) if i != 2]
-    assert g_rk4[:, others].max() <= 1.0                              # every other component is inside
-    assert abs(g_rk4.max() / g_gold.max() - 1) < 0.05                 # the gap IS the reference's noise
+    assert g_rk4[:, others].max() <= 1.0 and g_gold[:, others].max() <= 1.0    # every component but Ss is inside
 
 
 def test_philox_normals_are_standard():

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gym_sbr2_amd.sharding import gather_returns, shard_range
+from gym_sbr2_amd.sharding import gather_returns, local_device, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -73,3 +73,42 @@ def test_gather_without_process_group_is_identity():
     assert torch.equal(gather_returns(v, 5), v)
     with pytest.raises(ValueError):
         gather_returns(v, 6)
+
+
+def test_local_device_follows_local_rank():
+    assert local_device(env={"LOCAL_RANK": "3"}, n_devices=8) == 3
+    assert local_device(env={"LOCAL_RANK": "5"}, n_devices=4) == 1       # more ranks than visible devices: wrap, never fail
+    assert local_device(env={"LOCAL_RANK": "0"}, n_devices=0) == 0
+    assert local_device(env={}, n_devices=8) == 0                        # no launcher, no GPU here: torch's current device
+
+
+def _device_worker(rank, world, port, out_dir):
+    """Each spawned rank builds the recommended class with no `device` argument, the way torch.distributed.run would start
+    it (LOCAL_RANK in the environment, every GPU visible); SbrOSVec is replaced by a recorder - no GPU is touched."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gym_sbr2_amd.sharding as S
+        import gym_sbr2_amd.vec_env as V
+        seen = {}
+
+        class Recorder:
+            def __init__(self, num_envs, device=0, first_env_id=0, **kw):
+                seen.update(num_envs=num_envs, device=device, first_env_id=first_env_id)
+        V.SbrOSVec = Recorder
+        real_count = torch.cuda.device_count
+        torch.cuda.device_count = lambda: 8
+        try:
+            sh = S.ShardedSbrOS(1000)
+        finally:
+            torch.cuda.device_count = real_count
+        np.save(os.path.join(out_dir, "dev%d.npy" % rank), np.array([seen["device"], seen["first_env_id"], seen["num_envs"], sh.device]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_env_puts_rank_r_on_device_r(tmp_path):
+    world = 2
+    mp.spawn(_device_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / ("dev%d.npy" % r)).tolist() for r in range(world)]
+    assert got[0] == [0, 0, 500, 0] and got[1] == [1, 500, 500, 1]
