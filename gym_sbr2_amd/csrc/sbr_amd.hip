@@ -59,6 +59,39 @@ struct SbrBuf {
 #define SBR_STAMP(k, drain) do { } while (0)
 #endif
 
+// How the stepping kernels' stores leave the CU: 0 plain, 1 agent-scope write-through (sc1), 2 non-temporal (nt), 3 system-scope
+// write-through (sc0 sc1).  Plain stores leave ~21 MB dirty in the L2s for the end-of-kernel write-back, which then sits
+// between two dependent launches; written through, the bytes drain while other waves still compute.  Measured per k_step
+// launch (profiles/r02_notes.md): 65536 envs 16.06 -> 15.5 us, 131072 envs 28.6 -> 23.1 us; nt gains half of that at 65536 and
+// nothing at 131072; sc0 sc1 equals sc1.
+#ifndef SBR_ST_MODE
+#define SBR_ST_MODE 1
+#endif
+template <typename T>
+SBR_DEV void st_out(T* p, T v) {
+#if SBR_ST_MODE == 1
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif SBR_ST_MODE == 2
+    __builtin_nontemporal_store(v, p);
+#elif SBR_ST_MODE == 3
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *p = v;
+#endif
+}
+typedef unsigned int sbr_u32x4 __attribute__((ext_vector_type(4)));
+SBR_DEV void st_out16(sbr_u32x4* p, sbr_u32x4 v) {
+#if SBR_ST_MODE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif SBR_ST_MODE == 2
+    __builtin_nontemporal_store(v, p);
+#elif SBR_ST_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
 // Addressing.  An env is (i0, l): i0 = first env of the workgroup (wave-uniform, lives in SGPRs), l = threadIdx.x.  Every
 // access is written as (uniform pointer advanced to row and workgroup)[l], so the row arithmetic runs on the scalar unit
 // and the lane contributes one 32-bit offset (global_load v, v_off, s[base:base+1]).  The first version formed a 64-bit
@@ -73,7 +106,7 @@ SBR_DEV void load_x(const SbrBuf& b, int64_t i0, uint32_t l, double (&x)[SBR_NX]
 }
 SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[SBR_NX]) {
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) XROW(j) = x[j];
+    for (int j = 0; j < SBR_NX; ++j) st_out(&XROW(j), x[j]);
 }
 // INTERNAL controller layout [R_NROWS][N] (the public one of sbr_amd.h is produced by k_export / consumed by k_import):
 //  * the Kla history is a RING: the value of the j-th interval since reset sits in slot (j-1) % 10, where the interval
@@ -112,9 +145,9 @@ SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2,
 }
 // rows every step rewrites (the ring slot(s), return and meta are written by the caller)
 SBR_DEV void store_ctl(const SbrBuf& b, int64_t i0, uint32_t l, const SbrCtl& c) {
-    CTRL(R_T) = c.t; CTRL(R_SO_M1) = c.so_m1; CTRL(R_SO_M2) = c.so_m2;
-    CTRL(R_SNO_M1) = c.sno_m1; CTRL(R_SNO_M2) = c.sno_m2;
-    CTRL(R_IE_DO) = c.ie_do; CTRL(R_IE_EC) = c.ie_ec; CTRL(R_EC_LAST) = c.ec_last;
+    st_out(&CTRL(R_T), c.t); st_out(&CTRL(R_SO_M1), c.so_m1); st_out(&CTRL(R_SO_M2), c.so_m2);
+    st_out(&CTRL(R_SNO_M1), c.sno_m1); st_out(&CTRL(R_SNO_M2), c.sno_m2);
+    st_out(&CTRL(R_IE_DO), c.ie_do); st_out(&CTRL(R_IE_EC), c.ie_ec); st_out(&CTRL(R_EC_LAST), c.ec_last);
 }
 // whole history, logical order (oldest first), for the given interval count (per-lane slot: the general, slower form)
 SBR_DEV void load_ring(const SbrBuf& b, int64_t i0, uint32_t l, int k, double (&hist)[SBR_KLA_HIST]) {
@@ -337,7 +370,7 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
         for (int r = 0; r * 64 < CH; ++r) {
             const int c = r * 64 + (int)lane;
             if ((r + 1) * 64 <= CH || c < CH)
-                *reinterpret_cast<uint4*>(wdst + c * 16) = *reinterpret_cast<const uint4*>(stage + c * 16);
+                st_out16(reinterpret_cast<sbr_u32x4*>(wdst + c * 16), *reinterpret_cast<const sbr_u32x4*>(stage + c * 16));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             store_x(b, i0, l, x);
         } else {
 #pragma unroll
-            for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) XROW(j) = x[j];
+            for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) st_out(&XROW(j), x[j]);
         }
         store_ctl(b, i0, l, c);
         // the Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally
@@ -418,15 +451,15 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
             CTRL(R_QW) = qw;
         } else if (ring_uniform) {
-            CTRL(R_RING0 + kb_u) = c.knew[0];
-            if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb_u + 1)) = c.knew[1];
+            st_out(&CTRL(R_RING0 + kb_u), c.knew[0]);
+            if (c.n_new > 1) st_out(&CTRL(R_RING0 + ring_wrap(kb_u + 1)), c.knew[1]);
         } else {
             CTRL(R_RING0 + kb) = c.knew[0];
             if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
         }
         meta_unpack(my[11 * 64], steps, status, was_done);
-        CTRL(R_RET) = my[10 * 64] + r;
-        CTRL(R_META) = meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn);
+        st_out(&CTRL(R_RET), my[10 * 64] + r);
+        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn));
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
             rec[0] = c.t;
@@ -448,8 +481,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
         x6.get(xa6);
     }
     SBR_STAMP(5, false);                      // state stores issued
-    if (reward) (reward + i0)[l] = (OutT)r;
-    if (done) (done + i0)[l] = dn ? 1 : 0;
+    if (reward) st_out(&(reward + i0)[l], (OutT)r);
+    if (done) st_out(&(done + i0)[l], (uint8_t)(dn ? 1 : 0));
     const bool wide = __builtin_amdgcn_ballot_w64(true) == ~0ull;      // all 64 lanes of the wave hold an env
     char* stage = reinterpret_cast<char*>(wave_lds);
     if (obs) {
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
 
 // ------------------------------------------------------------------------------------------- rollout
 template <bool OCI>
-__global__ __launch_bounds__(SBR_BLOCK) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
+__global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
@@ -549,7 +582,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
 
 // SbrEnv2.step: one whole 12 h cycle per env (528 control intervals x 10 RK4 substeps) in one launch.
 template <typename OutT, typename ActT>
-__global__ __launch_bounds__(SBR_BLOCK) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
+__global__ __launch_bounds__(SBR_BLOCK, 2) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
@@ -745,6 +778,8 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.f2a = 1.0 / c.kh; p.f2b = c.Koh / c.kh;
     p.f4a = 1.0 / c.muA; p.f4b = c.Knh / c.muA;
     p.KohEtag = c.Koh * c.eta_g; p.etah_g = c.eta_h / c.eta_g;
+    p.bA_bH = c.bA / c.bH; p.n4_45b = p.n4_45 * c.bH; p.n12_45b = p.n12_45 * c.bH; p.n7_45b = p.n7_45 * c.bH;
+    p.n9_23 = p.n9_2 / p.n9_3; p.inv_n9_3 = 1.0 / p.n9_3;
     for (int k = 0; k < 8; ++k) p.t_ph[k] = c.t_cycle * c.t_ratio[k];
     p.cyc_Kc = c.cyc_Kc; p.cyc_KcI = c.cyc_Kc / c.cyc_tauI; p.cyc_KcD = c.cyc_Kc * c.cyc_tauD; p.cyc_dt = c.cyc_dt;
     p.substeps = c.substeps; p.terminal = c.terminal;
@@ -839,7 +874,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0) || !(c.cyc_tauI != 0) || !(c.cyc_dt > 0)) bad = "tauI must be non-zero, cyc_dt positive";
     // the rate constants that are folded into the Monod denominators (sbr_rates) must be positive and finite
     if (!(c.muH > 0 && c.muH < 1e300) || !(c.muA > 0 && c.muA < 1e300) || !(c.kh > 0 && c.kh < 1e300) ||
-        !(c.eta_g > 0 && c.eta_g < 1e300)) bad = "muH, muA, kh and eta_g must be positive";
+        !(c.eta_g > 0 && c.eta_g < 1e300) || !(c.bH > 0 && c.bH < 1e300) || !(c.Ya > 0 && c.Ya < 1e300))
+        bad = "muH, muA, kh, eta_g, bH and Ya must be positive";
     if (c.substeps > (1 << 20)) bad = "substeps out of range";
     for (int k = 0; k < 8; ++k) if (!(c.t_ratio[k] > 0)) bad = "t_ratio entries must be positive";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }

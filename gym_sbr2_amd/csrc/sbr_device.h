@@ -53,6 +53,9 @@ struct SbrPar {
     double f1a, f1b, f2a, f2b, f4a, f4b;
     double KohEtag;      // Koh * eta_g
     double etah_g;       // eta_h / eta_g
+    // rho4 + rho5 is carried as s45/bH = Xbh + (bA/bH) Xba, Sno's derivative as k/nu9_3: the factors sit in the coefficients
+    double bA_bH, n4_45b, n12_45b, n7_45b;    // bA/bH, nu4_45 bH, nu12_45 bH, nu7_45 bH
+    double n9_23, inv_n9_3;   // nu9_2 / nu9_3, 1 / nu9_3
     double t_ph[8];      // phase lengths t_cycle * t_ratio[k]                 (SBR_model_FB.py:18-27)
     double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
     // reciprocals of wave-uniform divisors, taken once on the host (an IEEE f64 division is ~19 issue slots on the device)
@@ -98,24 +101,27 @@ SBR_DEV void sbr_scatter(const double (&a)[SBR_NA], double (&x)[SBR_NX]) {
 
 // What the other derivatives are made of (the known-answer kernel k_rhs rebuilds all 14 from it; the integrator only
 // needs s45): rho1, rho2, rho3, rho6 and rho4 + rho5.
-struct SbrRho { double rho1, rho2, rho3, rho6, s45; };
+struct SbrRho { double rho1, rho2, rho3, rho6, s45b; };        // s45b = (rho4 + rho5)/bH
 
 // Conversion rates of the nine feedback components, incl. aeration.  Process rates :1660-1685, combination :1731-1755.
 //
-// fp64 VALU issue is the bound of every stepping kernel (4 cycles per instruction and wave, one wave per SIMD already
-// saturates it), so this function is written for INSTRUCTION COUNT, 55 + one v_rcp_f64 (the first version: 92 + 7):
+// fp64 VALU issue is the bound of every stepping kernel (one wave per SIMD issues a v_fma_f64 every 5.2 cycles, a
+// v_mul/v_add_f64 every 4.3, v_rcp_f64 costs 16: scripts/probes/fp64_issue.hip), so this function is written for
+// INSTRUCTION COUNT, 51 + one v_rcp_f64 (the first version: 92 + 7):
 //  * the reference's ten quotients need six denominators; all six reciprocals come from ONE v_rcp_f64 of their product,
-//    peeled apart as a tree (pairs first): 5 + 7 multiplications, dependency depth 3 + 3;
+//    peeled apart as a tree (pairs first): 5 + 8 multiplications, dependency depth 3 + 3;
 //  * the leading constants of the rates (muH, muA, kh, eta_g) are folded into the denominators on the host - a
-//    denominator (K + x)*c costs one FMA instead of one ADD, i.e. nothing - so that rho1, rho2, rho3, rho7 come out of
-//    the reciprocals already scaled: d1 = (Ks+Ss) kh/muH, d2 = (Koh+So)/kh, d4 = (Knh+Snh)/muA;
-//  * So/(Koh+So) and Koh/(Koh+So) share 1/d2, (Xs/Xbh)/(Kx + Xs/Xbh) is Xs/(Kx Xbh + Xs), and rho8 = (Xnd/Xs) rho7
-//    needs no 1/Xs because rho7 carries the factor Xs (also the continuous extension at Xs -> 0, where the reference
-//    evaluates 0/0);
-//  * rho4, rho5, rho6 are never formed: they enter the derivatives through FMAs.
+//    denominator (K + x)*c costs one FMA instead of one ADD - so that rho1, rho2, rho3, rho7 come out of the
+//    reciprocals already scaled: d1 = (Ks+Ss) kh/muH, d2 = (Koh+So)/kh, d4 = (Knh+Snh)/muA;
+//  * So/(Koh+So) and Koh/(Koh+So) share 1/d2, which is factored out of the hydrolysis bracket together with 1/d6;
+//    (Xs/Xbh)/(Kx + Xs/Xbh) is Xs/(Kx Xbh + Xs), and rho8 = (Xnd/Xs) rho7 needs no 1/Xs because rho7 carries the factor
+//    Xs (also the continuous extension at Xs -> 0, where the reference evaluates 0/0);
+//  * rho4, rho5, rho6 are never formed: they enter the derivatives through FMAs, decay as (rho4 + rho5)/bH with bH in the
+//    coefficients; Sno's derivative is returned divided by nu9_3 (the caller's step constants carry the factor).
 // 1/V is deliberately NOT part of the batch (see sbr_rk4): the six reciprocals of a lane are the same whether or not a
 // wave-mate doses carbon, so an env's arithmetic does not depend on which envs share its wavefront.
 // Parity is to tolerance, not bitwise (RHS known answers within 2e-15 relative).
+// Returns k[] = d/dt of the nine components, EXCEPT k[A_SNO] = (d Sno/dt)/nu9_3.
 SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, double kla_sat, double (&k)[SBR_NA],
                        SbrRho& o) {
     const double ss = a[A_SS], xs = a[A_XS], xbh = a[A_XBH], xba = a[A_XBA], so = a[A_SO], sno = a[A_SNO], snh = a[A_SNH],
@@ -131,29 +137,28 @@ SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, d
     const double rC = R * AB, rAB = R * Cc;
     const double rA = rAB * B;                                 // muH / ((Ks+Ss)(Koh+So))
     const double rB = rAB * A;                                 // muA / ((Knh+Snh)(Koa+So))
-    const double rc = rC * d6, rf = rC * d3, rb = rA * d1;     // 1/(Kno+Sno), 1/(Kx Xbh + Xs), kh/(Koh+So)
+    const double rc = rC * d6;                                 // 1/(Kno+Sno)
+    const double rfb = (rC * d3) * (rA * d1);                  // kh / ((Kx Xbh + Xs)(Koh+So))
     const double G = (ss * xbh) * rA;
     const double rho1 = G * so;                                // muH Ss/(Ks+Ss) So/(Koh+So) Xbh
     const double kw = p.KohEtag * (sno * rc);                  // eta_g Koh Sno/(Kno+Sno)
     const double rho2 = G * kw;                                // muH Ss/(Ks+Ss) Koh/(Koh+So) Sno/(Kno+Sno) eta_g Xbh
-    const double E = __builtin_fma(p.etah_g, kw * rb, so * rb);   // kh [So/(Koh+So) + eta_h Koh/(Koh+So) Sno/(Kno+Sno)]
-    const double c7 = (rf * E) * xbh;                          // rho7 / Xs
+    const double c7 = (rfb * __builtin_fma(p.etah_g, kw, so)) * xbh;   // rho7/Xs = kh [So + eta_h Koh Sno/(Kno+Sno)] Xbh / (d6 (Koh+So))
     const double rho7 = xs * c7, rho8 = xnd * c7;
     const double rho3 = ((snh * so) * rB) * xba;               // muA Snh/(Knh+Snh) So/(Koa+So) Xba
-    const double t4 = p.bH * xbh;                              // rho4
-    const double s45 = __builtin_fma(p.bA, xba, t4);           // rho4 + rho5
+    const double s45b = __builtin_fma(p.bA_bH, xba, xbh);      // (rho4 + rho5)/bH
     const double z = snd * xbh;                                // rho6 / ka
     const double s12 = rho1 + rho2;
     k[A_SS] = __builtin_fma(p.n2_12, s12, rho7);
-    k[A_XS] = __builtin_fma(p.n4_45, s45, -rho7);
-    k[A_XBH] = s12 - t4;
+    k[A_XS] = __builtin_fma(p.n4_45b, s45b, -rho7);
+    k[A_XBH] = __builtin_fma(-p.bH, xbh, s12);
     k[A_XBA] = __builtin_fma(-p.bA, xba, rho3);
     k[A_SO] = __builtin_fma(p.n8_1, rho1, __builtin_fma(p.n8_3, rho3, __builtin_fma(-kla, so, kla_sat)));   // + kla (So_sat - So)
-    k[A_SNO] = __builtin_fma(p.n9_2, rho2, p.n9_3 * rho3);
+    k[A_SNO] = __builtin_fma(p.n9_23, rho2, rho3);             // (nu9_2 rho2 + nu9_3 rho3)/nu9_3
     k[A_SNH] = __builtin_fma(p.n10_12, s12, __builtin_fma(p.n10_3, rho3, p.ka * z));
     k[A_SND] = __builtin_fma(-p.ka, z, rho8);
-    k[A_XND] = __builtin_fma(p.n12_45, s45, -rho8);
-    o.rho1 = rho1; o.rho2 = rho2; o.rho3 = rho3; o.rho6 = p.ka * z; o.s45 = s45;
+    k[A_XND] = __builtin_fma(p.n12_45b, s45b, -rho8);
+    o.rho1 = rho1; o.rho2 = rho2; o.rho3 = rho3; o.rho6 = p.ka * z; o.s45b = s45b;
 }
 
 // All 14 derivatives of one state, for the known-answer kernel only.  KIND 0: reaction_dxdt :1658-1787 (dosing ec,
@@ -166,8 +171,9 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
     sbr_gather(x, a);
     sbr_rates(p, a, kla, kla * p.So_sat, k, o);
     r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
+    k[A_SNO] = k[A_SNO] * p.n9_3;
     sbr_scatter(k, r);
-    r[7] = p.n7_45 * o.s45;
+    r[7] = p.n7_45b * o.s45b;
     r[13] = p.n13_1 * o.rho1 + p.n13_2 * o.rho2 + p.n13_3 * o.rho3 + p.n13_6 * o.rho6;
     if (KIND == 0) {
         const double q = ec * sbr_rcp(x[0]);
@@ -197,69 +203,85 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
 //   u = Salk - (Snh - Sno)/14       the charge balance u: the alkalinity row of the stoichiometry is (row Snh - row Sno)/14
 //                                   for every process (nu13_k = (nu10_k - nu9_k)/14 term by term, :1689-1725), so u only
 //                                   dilutes,
-//   Xp' = nu7 (rho4 + rho5) + (Q/V)(c_in - Xp): integrated with the others, but without a stage value when Q == 0.
-// With Q == 0 every flow term is an exact no-op (q = 0, g = 0), so a lane that doses nothing computes bit for bit the
-// same in the FLOW 1 code as in the FLOW 0 code: results do not depend on the wave-mates.
+//   Xp' = nu7 (rho4 + rho5) + (Q/V)(c_in - Xp): nothing depends on Xp, so without inflow it needs no stage value, only the
+//                                   weighted sum of rho4 + rho5 (one FMA per stage).
+// With Q == 0 every flow term is an exact no-op (q = 0, g = 0: each is a separate FMA whose product is then +-0), so a
+// lane that doses nothing computes bit for bit the same in the FLOW 1 code as in the FLOW 0 code: results do not depend
+// on the wave-mates.
 template <int FLOW>
 SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, double kla, double Q,
                      const double (&ld)[SBR_NX]) {
     const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+    // sbr_rates returns Sno's derivative over nu9_3 and decay over bH: their step constants carry the factors
+    const double g1 = h * p.n9_3, g2 = h2 * p.n9_3, g6 = h6 * p.n9_3, g3 = h3 * p.n9_3;
+    const double p2 = h2 * p.n7_45b, p1 = h * p.n7_45b, p6 = h6 * p.n7_45b, p3 = h3 * p.n7_45b;     // Xp' = nu7 bH s45b
     const double kla_sat = kla * p.So_sat;
     double a[SBR_NA], xp = x[7];
     sbr_gather(x, a);
     const double v0 = x[0], n0 = x[10] - x[9];                 // V and Snh - Sno at the start
     double v = v0, rv = FLOW ? sbr_rcp(v0) : 0.0;
     for (int s = 0; s < n; ++s) {
-        double k[SBR_NA], y[SBR_NA], acc[SBR_NA], k7, y7 = xp, acc7, q = 0.0;
+        double k[SBR_NA], y[SBR_NA], acc[SBR_NA], y7 = xp, acc7, q = 0.0, qn = 0.0;
         SbrRho o;
-        // what the inflow adds to the stage derivative of (w[], w7)
-        auto flow = [&](const double (&w)[SBR_NA], double w7) {
+        // what the inflow adds to the stage derivative of w[] (Sno's is carried over nu9_3: qn = q/nu9_3)
+        auto flow = [&](const double (&w)[SBR_NA]) {
             if (FLOW == 1) {
 #pragma unroll
-                for (int i = 0; i < SBR_NA; ++i) k[i] = __builtin_fma(q, i == A_SS ? (p.EC_conc - w[i]) : -w[i], k[i]);
-                k7 = __builtin_fma(-q, w7, k7);
+                for (int i = 0; i < SBR_NA; ++i)
+                    k[i] = __builtin_fma(i == A_SNO ? qn : q, i == A_SS ? (p.EC_conc - w[i]) : -w[i], k[i]);
             } else if (FLOW == 2) {
                 k[A_SS] = __builtin_fma(q, ld[2] - w[A_SS], k[A_SS]); k[A_XS] = __builtin_fma(q, ld[4] - w[A_XS], k[A_XS]);
                 k[A_XBH] = __builtin_fma(q, ld[5] - w[A_XBH], k[A_XBH]); k[A_XBA] = __builtin_fma(q, ld[6] - w[A_XBA], k[A_XBA]);
-                k[A_SO] = __builtin_fma(q, ld[8] - w[A_SO], k[A_SO]); k[A_SNO] = __builtin_fma(q, ld[9] - w[A_SNO], k[A_SNO]);
+                k[A_SO] = __builtin_fma(q, ld[8] - w[A_SO], k[A_SO]); k[A_SNO] = __builtin_fma(qn, ld[9] - w[A_SNO], k[A_SNO]);
                 k[A_SNH] = __builtin_fma(q, ld[10] - w[A_SNH], k[A_SNH]); k[A_SND] = __builtin_fma(q, ld[11] - w[A_SND], k[A_SND]);
                 k[A_XND] = __builtin_fma(q, ld[12] - w[A_XND], k[A_XND]);
-                k7 = __builtin_fma(q, ld[7] - w7, k7);
             }
         };
+        // Xp: acc7 += w_s (nu7 (rho4+rho5) + q (c_in - w7)), as two FMAs so that q == 0 is an exact no-op
+        auto xp_in = [&](double w7) { return FLOW == 2 ? ld[7] - w7 : -w7; };
         // stage 1 at (t, V)
-        sbr_rates(p, a, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
-        if (FLOW) { q = Q * rv; flow(a, xp); }
+        sbr_rates(p, a, kla, kla_sat, k, o);
+        if (FLOW) { q = Q * rv; qn = q * p.inv_n9_3; flow(a); }
 #pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h6, k[i], a[i]); y[i] = __builtin_fma(h2, k[i], a[i]); }
-        acc7 = __builtin_fma(h6, k7, xp); if (FLOW) y7 = __builtin_fma(h2, k7, xp);
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g6 : h6, k[i], a[i]); y[i] = __builtin_fma(i == A_SNO ? g2 : h2, k[i], a[i]);
+        }
+        acc7 = __builtin_fma(p6, o.s45b, xp);
+        if (FLOW) { y7 = __builtin_fma(h2 * q, xp_in(xp), __builtin_fma(p2, o.s45b, xp)); acc7 = __builtin_fma(h6 * q, xp_in(xp), acc7); }
         // stages 2 and 3 at (t + h/2, V + h/2 Q)
         if (FLOW) {
             const double vm = __builtin_fma(h2, Q, v);
             rv = FLOW == 1 ? sbr_rcp_refine(vm, rv) : sbr_rcp(vm);
-            q = Q * rv;
+            q = Q * rv; qn = q * p.inv_n9_3;
         }
-        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
-        if (FLOW) flow(y, y7);
+        sbr_rates(p, y, kla, kla_sat, k, o);
+        if (FLOW) flow(y);
+        acc7 = __builtin_fma(p3, o.s45b, acc7);
+        if (FLOW) { acc7 = __builtin_fma(h3 * q, xp_in(y7), acc7); y7 = __builtin_fma(h2 * q, xp_in(y7), __builtin_fma(p2, o.s45b, xp)); }
 #pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h3, k[i], acc[i]); y[i] = __builtin_fma(h2, k[i], a[i]); }
-        acc7 = __builtin_fma(h3, k7, acc7); if (FLOW) y7 = __builtin_fma(h2, k7, xp);
-        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
-        if (FLOW) flow(y, y7);
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g3 : h3, k[i], acc[i]); y[i] = __builtin_fma(i == A_SNO ? g2 : h2, k[i], a[i]);
+        }
+        sbr_rates(p, y, kla, kla_sat, k, o);
+        if (FLOW) flow(y);
+        acc7 = __builtin_fma(p3, o.s45b, acc7);
+        if (FLOW) { acc7 = __builtin_fma(h3 * q, xp_in(y7), acc7); y7 = __builtin_fma(h * q, xp_in(y7), __builtin_fma(p1, o.s45b, xp)); }
 #pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) { acc[i] = __builtin_fma(h3, k[i], acc[i]); y[i] = __builtin_fma(h, k[i], a[i]); }
-        acc7 = __builtin_fma(h3, k7, acc7); if (FLOW) y7 = __builtin_fma(h, k7, xp);
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g3 : h3, k[i], acc[i]); y[i] = __builtin_fma(i == A_SNO ? g1 : h, k[i], a[i]);
+        }
         // stage 4 at (t + h, V + h Q)
         if (FLOW) {
             v = __builtin_fma(h, Q, v);
             rv = FLOW == 1 ? sbr_rcp_refine(v, rv) : sbr_rcp(v);
-            q = Q * rv;
+            q = Q * rv; qn = q * p.inv_n9_3;
         }
-        sbr_rates(p, y, kla, kla_sat, k, o); k7 = p.n7_45 * o.s45;
-        if (FLOW) flow(y, y7);
+        sbr_rates(p, y, kla, kla_sat, k, o);
+        if (FLOW) flow(y);
 #pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(h6, k[i], acc[i]);
-        xp = __builtin_fma(h6, k7, acc7);
+        for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(i == A_SNO ? g6 : h6, k[i], acc[i]);
+        xp = __builtin_fma(p6, o.s45b, acc7);
+        if (FLOW) xp = __builtin_fma(h6 * q, xp_in(y7), xp);
     }
     sbr_scatter(a, x);
     x[7] = xp;
