@@ -8,14 +8,24 @@ CPU baseline.
 
 A "step" is one sbr_step() launch over this rank's batch: every env advances one control interval (two on the three
 phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
-    config2 (default)  65536 envs per GPU, stochastic influent (Philox normals drawn on the device), scenario = global env
-                       id mod 8, uniform random float32 set-points already resident in HBM, per-step API, RK4 h = dt.
-                       With N > 1 GPUs this is configs[3]'s shape (envs sharded by global id, one RCCL all-gather of the
-                       episode returns per episode, inside the timed region); per-GPU work is fixed => weak scaling.
+    config2 (default)  65536 envs per GPU, stochastic influent (Philox normals drawn on the device), per-call random float32
+                       set-points already resident in HBM, per-step API, RK4 h = dt.  With N > 1 GPUs the envs are sharded by
+                       global id through gym_sbr2_amd.ShardedSbrOS (the class the sharding tests cover) with one RCCL all-gather
+                       of the episode returns per episode inside the timed region: configs[3]'s shape at 65536 envs per GPU
+                       (per-GPU work fixed => weak scaling; 8 GPUs = 524288 envs = 2 x configs[3]'s 262144;
+                       `--envs-per-gpu 32768` gives configs[3] itself).
     config1            4096 envs per GPU, deterministic influent (64 wavefronts: cannot fill 1024 SIMDs; a parity case)
     config5            65536 envs per GPU, fused on-device random-policy rollout (sbr_rollout), 463 calls per launch
     cycle              65536 envs per GPU of the per-cycle env SBR-v2: one launch = one whole cycle of 528
                        control intervals; a "step" is then one cycle and `value` is still control intervals per second
+Policies (`--policy`):
+    physical (default) set-points u_DO ~ U[0, 2.5], u_EC ~ U[0, 15] per call on the four high-ammonia influent scenarios
+                       (4 + global id mod 4; the reference's own SbrOS uses scenario 6): every env stays inside the model's
+                       physical domain for the whole episode (`env_status.near_pole_frac_last_episode` = 0), so the timed
+                       trajectories are ones on which parity with the reference is defined and asserted
+                       (tests/test_gpu_parity.py::test_size_independent_properties_at_65536).
+    uniform            u_DO ~ U[0, 8], u_EC ~ U[0, 15] on all eight scenarios (round 1's workload): over-aerates, drives
+                       ammonia negative in 86 % of the envs (the reference model has no guards); cost is data-independent.
 Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase) runs INSIDE the timed region and is
 not counted as steps.  Before the W warm-up steps the same workload runs untimed for PRIME_SECONDS of wall time: the GPU needs
 ~25 ms of sustained work to reach its steady clocks (measured with scripts/probes/clock_ramp.py: 20.95 us per launch in the
@@ -35,14 +45,26 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the platform default; 
 ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
-# float64 operations per env-step, counted in the gfx950 ISA of the RK4 loop that runs when no lane of the wave doses carbon
-# (155 FMA x 2 + 172 MUL + 36 ADD + 4 RCP = 522 per substep, x 10 substeps; 682 per substep with dosing): a LOWER bound
-FP64_FLOP_PER_ENV_STEP = 5220
-FP64_VECTOR_PEAK_TFLOPS = 78.6         # /opt/skills/guides/MI355X_MICROARCH.md: vector float64
+# float64 operations per RK4 substep, counted in the gfx950 ISA of the two substep loops of k_step (round 2): when no lane of
+# the wave doses carbon 155 FMA x 2 + 112 MUL + 8 ADD + 4 RCP = 434; with dosing 209 x 2 + 124 + 12 + 4 = 558.  The loop only
+# (no PIDs, reward, observations): a LOWER bound of the work per env-step.
+FP64_FLOP_PER_SUBSTEP = {"plain": 434, "dosing": 558}
+SUBSTEPS = 10
+# vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
+# vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+MAX_CLOCK_GHZ = 2.4                    # the same guide, chip-level parameters
+SIMDS = 1024
 PRIME_SECONDS = 0.3                    # untimed: brings the GPU to steady clocks before warm-up and timing
+# phase schedule of an episode in calls (tests/golden/constants.npz): anoxic 46 intervals, aerobic 190, anoxic 171, aerobic 1
+ANOXIC_CALLS = [(0, 46), (235, 405)]   # calls whose interval doses carbon under a random NO3 set-point (boundary calls +-1)
+# the reference itself, measured in the build container by the survey: NOT this box, stated as such
+REFERENCE_CPU = {"value": 1880.0, "unit": "env-steps/s", "cores": 1, "value_8_processes": 14800.0,
+                 "hardware": "survey container, Intel Xeon @ 2.60 GHz, 8 logical cores (not the GPU box)",
+                 "what": "the unmodified Python reference (SbrOS, SciPy LSODA), one env per process, BASELINE.md section 2"}
 
 
-def cpu_baseline(n_envs=16384, calls=463):
+def cpu_baseline(n_envs=16384, calls=463, physical=True):
     """The CPU oracle (a C port of the same algorithm: RK4, fp64, OpenMP over envs) timed on this box's host cores, on a
     bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
     import numpy as np
@@ -50,11 +72,11 @@ def cpu_baseline(n_envs=16384, calls=463):
     from gym_sbr2_amd.vec_env import load_influent_tables
     means, stds = load_influent_tables()
     cores = min(len(os.sched_getaffinity(0)), 16)
-    scen = (np.arange(n_envs) % 8).astype(np.int32)
+    scen = ((4 + np.arange(n_envs) % 4) if physical else (np.arange(n_envs) % 8)).astype(np.int32)
     b = O.OracleBatch(n_envs, nthreads=cores)
     infl = b.mix(means, stds, scen, b.normals(0))
     rs = np.random.RandomState(0)
-    acts = [np.column_stack([rs.uniform(0, 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
+    acts = [np.column_stack([rs.uniform(0, 2.5 if physical else 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
     best = 0.0
     for _ in range(3):                 # best of three: shared hosts are noisy (about 0.5 s each: 7.6 M env-steps)
         b.reset(infl)
@@ -65,7 +87,8 @@ def cpu_baseline(n_envs=16384, calls=463):
         best = max(best, n_envs * calls / (time.perf_counter() - t0))
     return {"value": best, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d step() calls of the same workload, oracle/sbr_oracle.c with %d OpenMP threads, best of 3"
-                      % (n_envs, calls, cores)}
+                      % (n_envs, calls, cores),
+            "reference": REFERENCE_CPU}
 
 
 INTERVALS_PER_CYCLE = 528      # 24 + 48 + 223 + 186 + 11 + 36 control intervals (tests/golden/sbrv2_cycles.npz)
@@ -135,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config5", "cycle"])
     ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--policy", default="physical", choices=["physical", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -151,7 +175,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gym_sbr2_amd import SbrOSVec, _capi
+    from gym_sbr2_amd import ShardedSbrOS, _capi
     from gym_sbr2_amd.sharding import gather_returns
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,14 +199,20 @@ def main():
         return bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit)
     n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
     n_global = n_local * world
-    first = rank * n_local
-    env = SbrOSVec(n_local, device=local_rank, first_env_id=first, out_dtype=torch.float32)
+    physical = args.policy == "physical"
+    do_max = 2.5 if physical else 8.0
+    cfg = _capi.default_config()
+    cfg.act_DO_max = do_max               # what the fused rollout's on-device policy draws from (and clips to)
+    # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK
+    sh = ShardedSbrOS(n_global, rank=rank, world=world, out_dtype=torch.float32, config=cfg)
+    env, first = sh.env, sh.start
+    assert env.num_envs == n_local and env.device == dev, (env.num_envs, env.device, dev)
     gid = torch.arange(first, first + n_local, device=dev)
-    scenario = (gid % 8).to(torch.int32)
+    scenario = ((4 + gid % 4) if physical else (gid % 8)).to(torch.int32)
     rnd0 = torch.zeros(n_local, 48, dtype=torch.float64, device=dev) if args.workload == "config1" else None
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    pool = torch.rand(64, n_local, 2, device=dev, generator=gen) * torch.tensor([8.0, 15.0], device=dev)   # resident actions
+    pool = torch.rand(64, n_local, 2, device=dev, generator=gen) * torch.tensor([do_max, 15.0], device=dev)   # resident actions
     fused = args.workload == "config5"
     state = {"episode": 0, "in_episode": 0, "returns": None}
     seg_events = []
@@ -198,11 +228,10 @@ def main():
     def end_of_episode():
         # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync):
         # the per-env returns, collated over ranks by the one collective of the path (configs[3])
-        ret = env.episode_returns(out=ret64).to(torch.float32)
-        state["returns"] = gather_returns(ret, n_global) if (world > 1 or force_dist) else ret
+        state["returns"] = sh.gather_episode_returns_async(out64=ret64)      # all_gather_into_tensor when a group is up
         env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
 
-    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0}
+    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0}
 
     def run(k_steps, record):
         done = 0
@@ -227,6 +256,8 @@ def main():
             if record:
                 e1.record()
                 seg_events.append((e0, e1, m))
+                c0 = state["in_episode"]
+                acct["anoxic_calls"] += sum(max(0, min(c0 + m, hi) - max(c0, lo)) for lo, hi in ANOXIC_CALLS)
             state["in_episode"] += m
             done += m
 
@@ -267,22 +298,50 @@ def main():
     per_launch_s = dev_ms * 1e-3 / max(launches, 1)
     calls_per_launch = 1 if not fused else args.steps / max(len(seg_events), 1)
     achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
-    # HBM bytes per launch from the PMC counters: collected offline with rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE
-    # passes, gfx950 correction calibrated in the same run) and committed under profiles/; valid for this workload only
-    traffic, traffic_note = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not fused and n_local == 65536 and os.path.exists(pmc):
-        rec = json.load(open(pmc))
+    # HBM bytes per launch and VALU instructions per wave from the PMC counters: collected offline with rocprofv3 --pmc
+    # (scripts/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE / SQ passes, gfx950 fetch correction calibrated in the same
+    # run) and committed under profiles/; valid for the default workload only
+    traffic, traffic_note, valu_per_wave = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    rec = json.load(open(pmc)) if os.path.exists(pmc) else None
+    if rec and not fused and n_local == 65536 and args.workload == "config2":
         traffic = rec["hbm_bytes_per_launch"]
-        traffic_note = ("bytes per launch (profiles/r01_pmc_traffic.json: %.0f B per env-step vs %d algorithmic; the internal "
+        valu_per_wave = rec.get("valu_insts_per_wave")
+        traffic_note = ("bytes per launch (profiles/r02_pmc_traffic.json: %.0f B per env-step vs %d algorithmic; the internal "
                         "layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
                         % (rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
-    elif fused and n_local == 65536 and os.path.exists(pmc) and "rollout" in json.load(open(pmc)):
-        rec = json.load(open(pmc))["rollout"]
-        traffic = rec["hbm_bytes_per_launch"]
-        traffic_note = ("bytes per launch of %d calls (profiles/r01_pmc_traffic.json: %.1f B per env-step really moved; `achieved` "
-                        "uses the per-step convention of %d B)" % (rec["calls_per_launch"], rec["hbm_bytes_per_env_step"],
+    elif rec and fused and n_local == 65536 and "rollout" in rec:
+        rr = rec["rollout"]
+        traffic = rr["hbm_bytes_per_launch"]
+        traffic_note = ("bytes per launch of %d calls (profiles/r02_pmc_traffic.json: %.1f B per env-step really moved; `achieved` "
+                        "uses the per-step convention of %d B)" % (rr["calls_per_launch"], rr["hbm_bytes_per_env_step"],
                                                                   ALGO_BYTES_PER_ENV_STEP))
+    # float64 work of the timed calls: RK4 loop only, by the code path the timed calls ran (the anoxic phases dose carbon)
+    frac_dosing = acct["anoxic_calls"] / max(args.steps, 1)
+    flop_per_step = SUBSTEPS * (frac_dosing * FP64_FLOP_PER_SUBSTEP["dosing"] + (1 - frac_dosing) * FP64_FLOP_PER_SUBSTEP["plain"])
+    tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12
+    waves = (n_local + 63) // 64
+    fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+            "flop_per_env_step": flop_per_step, "dosing_share_of_timed_calls": frac_dosing,
+            "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work; one wave per SIMD issues a "
+                    "v_fma_f64 every 5.2 cycles and v_mul/v_add_f64 every 4.3 (scripts/probes/fp64_issue.hip), so ~0.8 of the "
+                    "nominal peak is what a single resident wave can reach"}
+    if valu_per_wave and not fused:
+        # share of the VALU issue slots of the launch that carried an instruction: instructions per wave x 4 cycles (one wave64
+        # fp64 instruction at the nominal rate) x waves per SIMD / (launch time x max clock)
+        fp64["issue_slot_frac"] = valu_per_wave * 4.0 * (waves / SIMDS if waves > SIMDS else 1.0) / (per_launch_s * MAX_CLOCK_GHZ * 1e9)
+        fp64["valu_insts_per_wave"] = valu_per_wave
+    workload = {"config1": "configs[1]: 4096 envs/GPU, fixed-step RK4 (10 substeps), deterministic influent, per-step API",
+                "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, fixed-step RK4 (10 substeps), per-step API",
+                "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload]
+    if n_local not in (4096, 65536):
+        workload = workload.replace("65536 envs/GPU", "%d envs/GPU" % n_local).replace("4096 envs/GPU", "%d envs/GPU" % n_local)
+    if world > 1:
+        rel = ("= configs[3]'s 262144" if n_global == 262144 else
+               "= %.3g x configs[3]'s 262144 (weak scaling keeps the 1-GPU line's per-GPU batch)" % (n_global / 262144.0))
+        workload += ("; configs[3] shape: sharded over %d GPUs by global env id (gym_sbr2_amd.ShardedSbrOS), one RCCL all-gather of the "
+                     "episode returns per episode inside the timed region; envs_total %d %s" % (world, n_global, rel))
+    st_bits = status_snap.to(torch.int64)
     out = {
         "metric": "env-steps/sec (batched)",
         "value": n_global * args.steps / elapsed,
@@ -291,13 +350,12 @@ def main():
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": {"config1": "configs[1]: 4096 envs/GPU, fixed-step RK4 (10 substeps), deterministic influent, per-step API",
-                                "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, fixed-step RK4 (10 substeps), "
-                                           "per-step API" + ("; sharded over %d GPUs with one RCCL all-gather of episode returns per "
-                                                             "episode (configs[3] shape)" % world if world > 1 else ""),
-                                "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload],
+        "config": {"workload": workload,
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
-                   "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS, "actions": "uniform random set-points, float32, resident in HBM",
+                   "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
+                   "policy": args.policy,
+                   "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
+                               "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
                    "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (2 if n_local > 98304 else 1)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -308,20 +366,20 @@ def main():
                      "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms,
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
                                          "host_in_reset_issue": acct["reset_issue_ms"]},
-                     "fp64_valu": {"achieved": n_local * calls_per_launch * FP64_FLOP_PER_ENV_STEP / per_launch_s / 1e12,
-                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": n_local * calls_per_launch * FP64_FLOP_PER_ENV_STEP / per_launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                   "flop_per_env_step": FP64_FLOP_PER_ENV_STEP,
-                                   "note": "informative: ISA count of the no-dosing RK4 loop (FMA = 2), a lower bound"},
-                     "note": "fp64 VALU-bound, not HBM-bound: >= 5.2 kFLOP per env-step at ~10 FLOP/B (SURVEY.md 8d); see DESIGN.md"},
-        "env_status": {"near_pole_frac_last_episode": float(((status_snap.to(torch.int64) & _capi.ST_NEAR_POLE) != 0).float().mean().item())
+                     "fp64_valu": fp64,
+                     "note": "the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
+                             "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu"},
+        "env_status": {"near_pole_frac_last_episode": float(((st_bits & _capi.ST_NEAR_POLE) != 0).float().mean().item())
                        if state["episode"] > 2 else None,
-                       "nonfinite": int(((status_snap.to(torch.int64) & _capi.ST_NONFINITE) != 0).sum().item()),
-                       "note": "uniform random set-points drive ammonia negative in most envs (the reference model has no "
-                               "guards); arithmetic cost is unaffected, see DESIGN.md"},
+                       "negative_frac_last_episode": float(((st_bits & _capi.ST_NEGATIVE) != 0).float().mean().item())
+                       if state["episode"] > 2 else None,
+                       "nonfinite": int(((st_bits & _capi.ST_NONFINITE) != 0).sum().item()),
+                       "note": "sticky per-env flags of the last finished episode (SBR_ST_* in include/sbr_amd.h): the physical policy "
+                               "keeps every env inside the model's domain; the uniform one drives ammonia negative in most envs (the "
+                               "reference model has no guards) - arithmetic cost is the same either way"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(physical=physical)
     env.close()
     if world > 1 or force_dist:
         dist.barrier()

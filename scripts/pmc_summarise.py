@@ -91,8 +91,8 @@ out = {
     "hbm_bytes_per_launch": fetch_b + write_b, "hbm_bytes_per_env_step": (fetch_b + write_b) / n_envs,
     "expected_from_code": {"read_bytes_per_env": 264,
                            "write_bytes_per_env": "313 when no lane of the wave dosed carbon (V, Si, Xi not stored), 337 otherwise",
-                           "note": "x 112 R; 18 ctrl rows R = 144; action 8 R; x 88-112 W; 11 ctrl rows W = 88; obs 72 + state 60 + "
-                                   "reward 4 + done 1 W"},
+                           "note": "x 112 R; 18 ctrl rows R = 144 (t, So[-1], Sno[-1], 2 integrals, EC[-1], return, meta, 10 ring "
+                                   "slots); action 8 R; x 88-112 W; 11 ctrl rows W = 88; obs 72 + state 60 + reward 4 + done 1 W"},
     "algorithmic_bytes_per_env_step": 513,
 }
 try:                                     # the fused rollout: one launch = a whole episode of 463 calls kept in registers
@@ -106,6 +106,18 @@ try:                                     # the fused rollout: one launch = a who
     print("k_rollout: %.2f MB per launch = %.2f B per env-step" % ((rf + rw) / 1e6, out["rollout"]["hbm_bytes_per_env_step"]))
 except SystemExit:
     print("no k_rollout dispatches in the PMC passes")
+try:                                     # dynamic VALU instructions per wave of k_step (SQ pass), for bench.py's issue_slot_frac
+    sq0 = counters("pmc_sq")
+    sk = pick(sq0["SQ_INSTS_VALU"], "k_step<")
+    out["valu_insts_per_wave"] = mean(sq0["SQ_INSTS_VALU"][sk]) / mean(sq0["SQ_WAVES"][sk])
+    out["sq_note"] = ("SQ pass of the same workload: SQ_INSTS_VALU / SQ_WAVES of %s; SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = %.3f, "
+                      "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f, SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f"
+                      % (short(sk), mean(sq0["SQ_ACTIVE_INST_ANY"][sk]) / mean(sq0["SQ_WAVE_CYCLES"][sk]),
+                         mean(sq0["SQ_WAIT_INST_ANY"][sk]) / mean(sq0["SQ_WAVE_CYCLES"][sk]),
+                         mean(sq0["SQ_WAIT_ANY"][sk]) / mean(sq0["SQ_WAVE_CYCLES"][sk])))
+    print("k_step: %.0f VALU instructions per wave" % out["valu_insts_per_wave"])
+except (SystemExit, KeyError, ZeroDivisionError):
+    print("no SQ pass: valu_insts_per_wave not recorded")
 json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print("k_step: fetch %.2f MB + write %.2f MB = %.1f B per env-step (factors %.4f / %.4f)"
       % (fetch_b / 1e6, write_b / 1e6, out["hbm_bytes_per_env_step"], f_factor, w_factor))

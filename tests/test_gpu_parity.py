@@ -613,6 +613,53 @@ def test_size_independent_properties_at_65536(G):
     env.close(); small.close()
 
 
+def test_bench_workload_parity_at_65536_with_the_physical_policy(G, tables):
+    """The workload bench.py times by default (BASELINE.json configs[2]: 65536 envs, stochastic influent, per-call random
+    set-points; `--policy physical`: u_DO ~ U[0, 2.5], u_EC ~ U[0, 15], scenarios 4..7) against the oracle, FREE-RUNNING over
+    the whole episode on a 512-env sample (first, middle and last wavefronts): the sample is never re-synchronised to the
+    device, so 463 calls of differences accumulate.  Under this policy every env stays inside the model's physical domain,
+    so the comparison is tight on ALL sampled envs (no env is excused), and the status row says so for all 65536."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 65536
+    pick = np.r_[0:192, n // 2:n // 2 + 128, n - 192:n]
+    gid = np.arange(n)
+    scen = (4 + gid % 4).astype(np.int32)
+    env = G.SbrOSVec(n)                                               # float32 actions and outputs, like the bench
+    obs = _np(env.reset(seed=1000, scenario=scen)).copy()
+    ora = O.OracleBatch(len(pick))
+    ora.first_env_id = 0
+    z = np.stack([O.OracleBatch(1, first_env_id=int(i)).normals(1000)[0] for i in pick])
+    oobs = ora.reset(ora.mix(means, stds, scen[pick], z))
+    assert np.abs(obs[pick] - oobs).max() < 1e-5
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    pool = torch.rand(64, n, 2, device="cuda", generator=gen) * torch.tensor([2.5, 15.0], device="cuda")
+    worst, ret = 0.0, np.zeros(len(pick))
+    for c in range(463):
+        a = pool[c & 63]
+        o, s_, r, d = env.step(a)
+        oo, os_, orr, od = ora.step(_np(a)[pick].astype(np.float64))
+        ret += orr
+        assert np.array_equal(_np(d)[pick], od)
+        if c % 20 == 0 or c >= 460:
+            x, ctrl = env.get_state()
+            g = gate(_np(x).T[pick], ora.envs["x"]).max()
+            worst = max(worst, g)
+            assert g < 1e-6, (c, g)                                   # free-running, every sampled env
+            assert np.allclose(_np(r)[pick], orr, rtol=2e-7, atol=1e-10) and np.abs(_np(o)[pick] - oo).max() < 1e-5
+    x, ctrl = env.get_state()
+    ctrl = _np(ctrl)
+    # all 65536 envs stay clear of the Monod poles and finite; a handful (measured 9 of 65536) dip a concentration below
+    # -1e-6 (SBR_ST_NEGATIVE), which the sampled envs - asserted tightly above whatever their flags - may or may not include
+    st = ctrl[_capi.C_STATUS].astype(np.int64)
+    assert np.all((st & (_capi.ST_NEAR_POLE | _capi.ST_NONFINITE)) == 0) and ((st & _capi.ST_NEGATIVE) != 0).mean() < 1e-3
+    assert np.array_equal(st[pick], ora.envs["status"].astype(np.int64))
+    assert np.all(ctrl[_capi.C_DONE] == 1) and np.abs(ctrl[_capi.C_RETURN][pick] - ret).max() < 1e-10
+    assert np.abs(ctrl[_capi.C_QW][pick] / ora.envs["qw"] - 1).max() < 1e-9
+    print("bench workload (physical policy), free-running sample: worst gate %.3e" % worst)
+    env.close()
+
+
 def test_indexing_at_134_million_envs(G):
     """Maximum sizes: 2**27 envs in ONE handle (51 GB of plant/controller/influent rows; element indices into the ctrl
     block pass 2**31 from row 16 on, obs offsets pass 2**31 at env 119 M).  Envs are independent and keyed by their global
@@ -923,20 +970,26 @@ def test_results_do_not_depend_on_wave_mates_or_shard_boundaries(G, tables):
     only, so a non-dosing lane rounded differently next to a dosing wave-mate.)"""
     n, cut, calls = 200, 77, 70
     rs = np.random.RandomState(5)
-    acts = np.stack([np.column_stack([rs.uniform(0, 8, n), np.where(rs.rand(n) < 0.5, 0.0, rs.uniform(0, 15, n))]) for _ in range(calls)])
+    # NO3 set-point 0 => error Sno - 0 > 0 => the valve opens; set-point 15 => error < 0 => EC stays clamped at 0
+    acts = np.stack([np.column_stack([rs.uniform(0, 8, n), np.where(rs.rand(n) < 0.5, 0.0, 15.0)]) for _ in range(calls)])
     scen = (np.arange(n) % 8).astype(np.int32)
 
     def run(lo, hi):
         env = G.SbrOSVec(hi - lo, first_env_id=lo, out_dtype=torch.float64, action_dtype=torch.float64)
         env.reset(seed=9, scenario=scen[lo:hi])
+        ec_mid = None
         for c in range(calls):
             env.step(torch.from_numpy(acts[c, lo:hi]).cuda())
+            if c == 30:                                        # inside the first anoxic phase
+                ec_mid = _np(env.ctrl_row(7)).copy()
         x, ctrl = env.get_state()
-        out = (_np(x).copy(), _np(ctrl).copy())
+        out = (_np(x).copy(), _np(ctrl).copy(), ec_mid)
         env.close()
         return out
-    xa, ca = run(0, n)
-    assert (ca[7] == 0).any() and (ca[7] != 0).any()          # EC[-1]: some lanes dosed on the last anoxic call, others did not
+    xa, ca, eca = run(0, n)
+    for w in range(0, n - 63, 64):                             # EC[-1] on an anoxic call: every full wave mixes dosing and idle lanes
+        assert (eca[w:w + 64] == 0).any() and (eca[w:w + 64] != 0).any(), w
+    assert np.all(ca[0] > 0.0641667)                           # and the run went on into the aerobic phase (t > T3_0)
     for lo, hi in ((0, cut), (cut, n), (130, 131)):
-        xs, cs = run(lo, hi)
-        assert np.array_equal(xs, xa[:, lo:hi]) and np.array_equal(cs, ca[:, lo:hi]), (lo, hi)
+        xs, cs, ecs = run(lo, hi)
+        assert np.array_equal(xs, xa[:, lo:hi]) and np.array_equal(cs, ca[:, lo:hi]) and np.array_equal(ecs, eca[lo:hi]), (lo, hi)
