@@ -470,10 +470,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const
             rec[SBR_TR_U_DO * b.n_trace] = c.u_do; rec[SBR_TR_U_EC * b.n_trace] = c.u_ec;
             rec[SBR_TR_E_EC * b.n_trace] = c.e_ec; rec[SBR_TR_IE_EC * b.n_trace] = c.ie_ec; rec[SBR_TR_DCV_EC * b.n_trace] = c.dcv_ec;
             // module_reward_EQIOCI.py:60-112: EQI2, and the cost terms over their maxima (Kla = 240, EC = 0.0005 throughout)
-            const double td = 0.002 / 24;
-            const double ae_max = 1.32 * (240 * 11) * td * (8 / ((td * 11) * 1.8 * 1000));
-            const double ec_max = p.EC_conc * (0.0005 * 11) * td / ((td * 11) * 1000);
-            const double ae2 = rp.ae / ae_max, ec2 = rp.ec / ec_max;
+            const double ae2 = rp.ae * p.inv_ae_max, ec2 = rp.ec * p.inv_ec_max;
             rec[SBR_TR_R_EQI * b.n_trace] = rp.eqi2; rec[SBR_TR_R_OCI * b.n_trace] = ae2 + ec2;
             rec[SBR_TR_R_AE * b.n_trace] = ae2; rec[SBR_TR_R_EC * b.n_trace] = ec2;
         }
@@ -788,6 +785,11 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.random_scenario = c.random_scenario;
     p.inv_dt = 1.0 / c.dt; p.inv_t_delta = 1.0 / c.t_delta; p.inv_substeps = 1.0 / (double)c.substeps;
     p.inv_cyc_dt = 1.0 / c.cyc_dt; p.h_fill = c.T_fill / (double)p.fill_rows;
+    {   // module_reward_EQIOCI.py:72, :80 - Kla = 240 and EC = 0.0005 over eleven rows of its own t_delta = 0.002/24, So_sat = 8
+        const double td = 0.002 / 24;
+        p.inv_ae_max = 1.0 / (1.32 * (240 * 11) * td * (8 / ((td * 11) * 1.8 * 1000)));
+        p.inv_ec_max = 1.0 / (c.EC_conc * (0.0005 * 11) * td / ((td * 11) * 1000));
+    }
     p.rows10_min = rows_threshold(c.dt, 10); p.rows9_min = rows_threshold(c.dt, 9);
 }
 

@@ -60,6 +60,7 @@ struct SbrPar {
     double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
     // reciprocals of wave-uniform divisors, taken once on the host (an IEEE f64 division is ~19 issue slots on the device)
     double inv_dt, inv_t_delta, inv_substeps, inv_cyc_dt, h_fill;
+    double inv_ae_max, inv_ec_max;   // 1 / AE_OCI_max, 1 / EC_OCI_max of module_reward_EQIOCI.py:72, :80 (trajectory export)
     // len(t_range) = int(span/dt) of a control interval (:1339, :1384) is 10 iff span >= rows10_min and 9 iff
     // rows9_min <= span < rows10_min: the smallest doubles whose IEEE quotient by dt reaches 10.0 / 9.0 (found on the
     // host by stepping through neighbouring doubles), so the common case costs two comparisons and stays exact
@@ -537,12 +538,13 @@ SBR_DEV void sbr_write_state(OutT* s, int st, double t_obs, const double (&x)[SB
 // settle: layer concentrations after t_set (closed form, see above); returns Xf
 SBR_DEV double sbr_settle(const SbrPar& p, const double (&x)[SBR_NX], double t_set, double (&sx)[10]) {
     const double xf = 0.75 * (x[3] + x[4] + x[5] + x[6] + x[7]);
-    const double z = x[0] / p.settler_area;
-    const double a = p.settler_vmax / z * t_set, ea = exp(-a);
+    // a = vmax / z * t_set with z = V / area; quotients by per-lane values go through sbr_rcp (1 ulp), those by constants are
+    // folded: the terminal phases run once per episode, but an IEEE f64 division is ~30 instructions of kernel text each
+    const double a = (p.settler_vmax * t_set) * (p.settler_area * sbr_rcp(x[0])), ea = exp(-a);
     // sX[9-j] = Xf e^-a sum_{m<=j} a^m/m!, sX[0] = 10 Xf - sum(others)
     double term = 1.0, partial = 0.0, others = 0.0;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= a / (double)(j + 1); }
+    for (int j = 0; j < 9; ++j) { partial += term; sx[9 - j] = xf * ea * partial; term *= a * (1.0 / (double)(j + 1)); }
 #pragma unroll
     for (int j = 1; j < 10; ++j) others += sx[j];
     sx[0] = 10.0 * xf - others;
@@ -553,9 +555,9 @@ SBR_DEV double sbr_settle(const SbrPar& p, const double (&x)[SBR_NX], double t_s
 // sx_eff, the sludge that left with the effluent (sum(sX[-m:-1]*layer_volume), which drops the last layer)
 SBR_DEV double sbr_draw(const SbrPar& p, double (&x)[SBR_NX], const double (&sx)[10], double xf, double& sx_eff) {
     const double vs = x[0];
-    const double layer_v = vs / 10;
+    const double layer_v = vs * 0.1;
     double resid_v = vs - p.Qeff;
-    int m = (int)ceil(rint(p.Qeff / layer_v));        // python round() is half-to-even = rint
+    int m = (int)ceil(rint(p.Qeff * sbr_rcp(layer_v)));   // python round() is half-to-even = rint; Qeff/layer_v = 5.0 in the reference's setup
     m = m < 1 ? 1 : (m > 9 ? 9 : m);
     const int nl = 10 - m;                            // layers that stay
     double wsum = 0.0, se = 0.0;
@@ -563,25 +565,33 @@ SBR_DEV double sbr_draw(const SbrPar& p, double (&x)[SBR_NX], const double (&sx)
     for (int i = 0; i < 9; ++i) { if (i < nl) wsum = wsum + layer_v * sx[i]; else se = se + sx[i] * layer_v; }
     sx_eff = se;
     double waste = wsum - p.biomass_setpoint * resid_v;
-    double qw = __builtin_nan("");
-    bool open = true;
+    // the wastage loop (:2363-2382) removes whole layers from the top while more than a layer's sludge is to go, then a
+    // part qw of the next one: find that layer first, take ONE quotient, then sum what remains in layer order
+    int part = -1;                                    // index of the partially wasted layer
+    double qnum = __builtin_nan(""), qden = 1.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if (i < nl && part < 0) {
+            const double rest = waste - layer_v * sx[i];
+            if (rest > 0) { waste = rest; resid_v -= layer_v; }
+            else { part = i; qnum = waste; qden = sx[i] - p.biomass_setpoint; }
+        }
+    }
+    const double qw = qnum * sbr_rcp(qden);
+    if (part >= 0) resid_v -= qw;
     double wkeep = 0.0;                               // sum of the weights that remain, in layer order
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        if (i < nl) {
+        if (i < nl && part >= 0 && i >= part) {
             double w = layer_v * sx[i];
-            if (open) {
-                const double rest = waste - w;
-                if (rest > 0) { waste = rest; w = 0.0; resid_v -= layer_v; }
-                else { qw = waste / (sx[i] - p.biomass_setpoint); w = w - qw * sx[i]; resid_v -= qw; open = false; }
-            }
+            if (i == part) w = w - qw * sx[i];
             wkeep = wkeep + w;
         }
     }
-    const double sx2 = wkeep / resid_v;
+    const double scale = (1 / 0.75) * (wkeep * sbr_rcp(resid_v)) * sbr_rcp(xf);
     x[0] = resid_v;
 #pragma unroll
-    for (int i = 3; i <= 7; ++i) x[i] = x[i] * (1 / 0.75) * sx2 / xf;
+    for (int i = 3; i <= 7; ++i) x[i] = x[i] * scale;
     return qw;
 }
 
@@ -603,7 +613,7 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    sbr_rk4<0>(p, x, span / (double)(n > 0 ? n : 1), n, kla, 0.0, nold);
+    sbr_rk4<0>(p, x, span * sbr_rcp((double)(n > 0 ? n : 1)), n, kla, 0.0, nold);
     sbr_hist_push(hist, kla);                         // Kla.append in Sim_idle (:2578)
     c.kla_last = kla;
     return qw;
