@@ -92,6 +92,14 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise SbrError("libsbr_amd.so is missing (%s); run python -c 'import __graft_entry__ as g; g.build()'" % path)
         _build.build_library()
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Whichever HIP runtime is mapped first serves the whole
+    # process, and with this library first (system ROCm) and torch second the device enumeration of the later one fails
+    # ("no HIP device visible", seen when build() and smoke() ran in one process).  torch owns the device memory this package
+    # works on, so its runtime goes first - always the same order, the one every test exercises.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         try:

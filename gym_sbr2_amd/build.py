@@ -16,7 +16,10 @@ DEPS = [SRC, os.path.join(_HERE, "csrc", "sbr_device.h"),
         os.path.join(os.path.dirname(_HERE), "include", "sbr_amd.h")]
 LIB = os.path.join(_HERE, "lib", "libsbr_amd.so")
 HASH = LIB + ".srchash"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math"]
+# -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's argument segment arrive in SGPRs at wave launch (gfx940+);
+# k_step's leading arguments are the pointers its first loads need (-0.5 us per launch at small batches, profiles/r02_notes.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def hipcc():

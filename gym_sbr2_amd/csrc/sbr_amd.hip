@@ -380,10 +380,16 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
     }
 }
 
+// The first eight arguments (16 dwords) are what the first global loads need; the library is built with
+// -mllvm -amdgpu-kernarg-preload-count=16, so a wave starts with them in SGPRs and issues its loads without waiting for a
+// scalar load of the argument segment (two serial scalar round trips before: n for the bounds test, then the pointers).
 template <typename OutT, typename ActT, int W, bool OCI>
-__global__ __launch_bounds__(SBR_BLOCK, W) void k_step(SbrPar p, SbrBuf b, const ActT* __restrict__ action,
-                                                      OutT* __restrict__ obs, OutT* __restrict__ state,
-                                                      OutT* __restrict__ reward, uint8_t* __restrict__ done) {
+__global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
+                                                      const ActT* __restrict__ action, OutT* __restrict__ obs,
+                                                      OutT* __restrict__ state, OutT* __restrict__ reward,
+                                                      uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
+    SbrBuf b = b0;
+    b.x = bx; b.ctrl = bctrl; b.n = bn;
     // wave-major: wave w owns park[w][slot][64], 18 (19) slots x 512 B = 9216 B, which is also what 64 float64 observation
     // rows take when the region is reused for the output transpose
     constexpr int NSLOT = SBR_NPARK + (OCI ? 1 : 0);
@@ -798,11 +804,11 @@ static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state
                           hipStream_t st) {
     const dim3 grid((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK));
     if (e->n > 98304)      // more than 1.5 waves per SIMD on 1024 SIMDs: the two-waves-per-SIMD build wins
-        hipLaunchKernelGGL((k_step<OutT, ActT, 2, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
-                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+        hipLaunchKernelGGL((k_step<OutT, ActT, 2, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->buf.x, e->buf.ctrl, e->buf.n,
+                           (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
-        hipLaunchKernelGGL((k_step<OutT, ActT, 1, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->par, e->buf, (const ActT*)action,
-                           (OutT*)obs, (OutT*)state, (OutT*)reward, done);
+        hipLaunchKernelGGL((k_step<OutT, ActT, 1, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->buf.x, e->buf.ctrl, e->buf.n,
+                           (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
 }
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
