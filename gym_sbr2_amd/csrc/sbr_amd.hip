@@ -342,7 +342,32 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // xdot start values: 17 doubles per lane, 18 with the operating-cost reward's running sum) are parked in LDS, not in
 // VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and the RK4 loop keeps its registers
 // (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at park[(w*NSLOT + j)*64 + l] (conflict-free).
-#define SBR_NPARK (SBR_KLA_HIST + 2 + SBR_NXD)
+// LDS slots of a lane in k_step: the Kla ring as loaded (physical slot order) in 0..9 and AGAIN in 10..17 (slots 0..7), so
+// that entry i of the logical tail, ring slot (kb + i) mod 10, is simply LDS slot kb + i: one per-lane base address and
+// constant offsets, no wrap arithmetic per read; then return, meta, the six xdot start values (and the OCI running sum).
+#define SBR_RING2 (2 * SBR_KLA_HIST - 2)
+#define SBR_NPARK (SBR_RING2 + 2 + SBR_NXD)
+// k_step's Kla history.  Nothing is shifted: the reward reads the eight or nine entries it sums, the new value(s) go
+// straight to their ring slot in HBM.  Only the terminal call needs the whole tail (it rewrites the ring).
+struct SbrHistLds {
+    const double* base;                   // the lane's slot kb: entry i of the tail before this call's appends is base[i * 64]
+    double last, idle; bool idle_pushed;  // old(9) = Kla[-1] is in a register; idle = Sim_idle's append
+    SBR_DEV double old(int i) const { return i == SBR_KLA_HIST - 1 ? last : base[i * 64]; }
+    SBR_DEV double commit_and_window(const SbrCtl& c) const { return sbr_kla_window(c, *this); }
+    SBR_DEV void push(double k) { idle = k; idle_pushed = true; }
+    // the tail after this call's appends (and idle's), oldest first
+    SBR_DEV void tail(const SbrCtl& c, double (&h)[SBR_KLA_HIST]) const {
+        double all[SBR_KLA_HIST + 3];     // old(0..9), knew[0], knew[1], idle - compacted: unused appends are skipped
+#pragma unroll
+        for (int j = 0; j < SBR_KLA_HIST; ++j) all[j] = old(j);
+        all[10] = c.n_new > 0 ? c.knew[0] : idle;
+        all[11] = c.n_new > 1 ? c.knew[1] : idle;
+        all[12] = idle;
+        const int shift = c.n_new + (idle_pushed ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < SBR_KLA_HIST; ++j) h[j] = shift == 0 ? all[j] : shift == 1 ? all[j + 1] : shift == 2 ? all[j + 2] : all[j + 3];
+    }
+};
 
 // One output row per lane (obs: 18 values, state: 15) -> the caller's row-major tensor.  A full wavefront owns 64
 // consecutive rows, i.e. ONE contiguous block of 64 x NV x sizeof(OutT) bytes (4608 B of float32 observations): the rows go
@@ -390,8 +415,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
     SbrBuf b = b0;
     b.x = bx; b.ctrl = bctrl; b.n = bn;
-    // wave-major: wave w owns park[w][slot][64], 18 (19) slots x 512 B = 9216 B, which is also what 64 float64 observation
-    // rows take when the region is reused for the output transpose
+    // wave-major: wave w owns park[w][slot][64], 26 (27) slots x 512 B = 13 KiB; the region is reused for the output
+    // transpose (64 float64 observation rows take 9216 B)
     constexpr int NSLOT = SBR_NPARK + (OCI ? 1 : 0);
     __shared__ __attribute__((aligned(16))) double park[NSLOT * SBR_BLOCK];
     const uint32_t l = threadIdx.x;
@@ -410,12 +435,17 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) my[j * 64] = CTRL(R_RING0 + j);       // physical slot order
-    my[10 * 64] = CTRL(R_RET); my[11 * 64] = meta0;
-    SbrX6Lds x6{my + 12 * 64};
+    for (int j = 0; j < SBR_KLA_HIST; ++j) {               // physical slot order, slots 0..7 twice
+        const double v = CTRL(R_RING0 + j);
+        my[j * 64] = v;
+        if (j < SBR_RING2 - SBR_KLA_HIST) my[(SBR_KLA_HIST + j) * 64] = v;
+    }
+    my[SBR_RING2 * 64] = CTRL(R_RET); my[(SBR_RING2 + 1) * 64] = meta0;
+    SbrX6Lds x6{my + (SBR_RING2 + 2) * 64};
     if (OCI) my[SBR_NPARK * 64] = CTRL(R_KSUM);           // only this reward keeps the running sum of Kla
     x6.put(x);
     const int kb = ring_k(p, c.t) % SBR_KLA_HIST;          // slot of the oldest entry = where the next Kla goes
+    const double* tail0 = my + kb * 64;                    // entry i of the logical tail: tail0[i * 64], i = 0..8
     c.kla_last = my[ring_wrap(kb + SBR_KLA_HIST - 1) * 64];
     const double kla_before = c.kla_last;
     SBR_STAMP(1, true);                       // every load has returned, the parked values are in LDS
@@ -423,19 +453,17 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
     bool dn = true;
     double xa6[SBR_NXD];
     if (((int)meta0 & 1) == 0) {          // not done: a finished env waits for sbr_reset (the reference leaves resetting to the caller)
-        double qw = 0.0, hist[SBR_KLA_HIST];
+        double qw = 0.0;
         int steps, status; bool was_done;
         SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
         SBR_STAMP(2, false);
         sbr_run_intervals(p, c, x, a0, a1, x6);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
-#pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST - 1; ++j) hist[j] = my[ring_wrap(kb + j) * 64];      // logical order, oldest first
-        hist[SBR_KLA_HIST - 1] = kla_before;
+        SbrHistLds hs{tail0, kla_before, 0.0, false};
         x6.get(xa6);
         double ksum = OCI ? my[SBR_NPARK * 64] : 0.0;
-        r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum, rp);
+        r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
@@ -454,6 +482,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
         const int kb_u = __builtin_amdgcn_readfirstlane(kb);
         const bool ring_uniform = __builtin_amdgcn_ballot_w64(kb != kb_u) == 0ull;
         if (dn && p.terminal) {           // the idle phase appended one more Kla: the logical history moved by n_new + 1
+            double hist[SBR_KLA_HIST];
+            hs.tail(c, hist);
             store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
             CTRL(R_QW) = qw;
         } else if (ring_uniform) {
@@ -463,8 +493,8 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
             CTRL(R_RING0 + kb) = c.knew[0];
             if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
         }
-        meta_unpack(my[11 * 64], steps, status, was_done);
-        st_out(&CTRL(R_RET), my[10 * 64] + r);
+        meta_unpack(my[(SBR_RING2 + 1) * 64], steps, status, was_done);
+        st_out(&CTRL(R_RET), my[SBR_RING2 * 64] + r);
         st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn));
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
@@ -531,7 +561,8 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
         bool dn;
         sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
-        const double r = sbr_finish_step<OCI>(p, c, hist, x, xa6, t_obs, dn, qw, ksum, rp);
+        SbrHistReg hs{hist};
+        const double r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         acc += r; ret += r; status |= c.st_new;
         if (steps < SBR_MAX_STEPS) steps += 1;
         if (dn) finished = true;

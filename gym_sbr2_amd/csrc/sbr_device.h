@@ -450,12 +450,51 @@ SBR_DEV void sbr_hist_apply(const SbrCtl& c, double (&hist)[SBR_KLA_HIST]) {
     if (c.n_new > 0) sbr_hist_push(hist, c.knew[0]);
     if (c.n_new > 1) sbr_hist_push(hist, c.knew[1]);
 }
+// Where a kernel keeps the Kla history.  old(i), i = 0..9, is the list's tail BEFORE this call's appends (oldest first,
+// old(9) = Kla[-1]); commit_and_window() applies the appends and returns the reward's window sum; push() is Sim_idle's
+// extra append.
+struct SbrHistReg {                       // the fused kernels: ten registers, shifted in place
+    double (&h)[SBR_KLA_HIST];
+    SBR_DEV double old(int i) const { return h[i]; }
+    SBR_DEV void push(double k) { sbr_hist_push(h, k); }
+    // apply this call's appends and return sum(Kla[-rows:-1]) of the list as it then stands (module_reward_EQIOCI.py:70),
+    // left to right like python's sum(): the rows-1 values before the current one
+    SBR_DEV double commit_and_window(const SbrCtl& c) {
+        sbr_hist_apply(c, h);
+        double s = (c.rows >= 10) ? h[0] : 0.0;          // 9 previous values if rows == 10, else 8
+#pragma unroll
+        for (int j = 1; j < SBR_KLA_HIST - 1; ++j) s = s + h[j];
+        return s;
+    }
+};
+// sum(Kla[-rows:-1]) AFTER this call's n_new appends (module_reward_EQIOCI.py:70), taken from the tail before them: the
+// list then ends ..., old(n_new), ..., old(9), knew[0 .. n_new-1], and the slice is the rows-1 entries before the last one.
+// Left to right like python's sum().
+template <typename H>
+SBR_DEV double sbr_kla_window(const SbrCtl& c, const H& hs) {
+    const bool nine = c.rows >= 10;       // 9 previous values if rows == 10, else 8
+    double s;
+    if (c.n_new == 1) {
+        s = nine ? hs.old(1) : 0.0;
+#pragma unroll
+        for (int i = 2; i <= 9; ++i) s = s + hs.old(i);
+    } else if (c.n_new >= 2) {
+        s = nine ? hs.old(2) : 0.0;
+#pragma unroll
+        for (int i = 3; i <= 9; ++i) s = s + hs.old(i);
+        s = s + c.knew[0];
+    } else {                              // no interval ran (t is NaN or out of range): the list is unchanged
+        s = nine ? hs.old(0) : 0.0;
+#pragma unroll
+        for (int i = 1; i <= 8; ++i) s = s + hs.old(i);
+    }
+    return s;
+}
 
 // module_reward_EQIOCI.py:4-115.  Kla got one append per interval, EC got rows-1:  Kla[-rows:-1] is
-// the rows-1 values BEFORE the current one, EC[-rows:-1] = last value of the previous interval +
+// the rows-1 values BEFORE the current one (ksum, see sbr_kla_window), EC[-rows:-1] = last value of the previous interval +
 // (rows-2) x current.
-SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)[SBR_KLA_HIST], const double (&x)[SBR_NX],
-                          SbrRewardParts& rp) {
+SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, double ksum, const double (&x)[SBR_NX], SbrRewardParts& rp) {
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
     const double bio = xbh + xba, part = (xs + xi) + (bio + xp);
     const double snkj = x[10] + x[11] + x[12] + 0.08 * bio + 0.06 * (xp + xi);
@@ -464,9 +503,6 @@ SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, const double (&hist)
     // EQI :40-47 with SS = 0.75 part; EQI2 = EQI/10 (:60); the constant divisors are folded (<= 1 ulp each)
     const double eqi2 = (1.5 * part + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (0.66 / 1000 / 10);
     const double td = 0.002 / 24;
-    double ksum = (c.rows >= 10) ? hist[0] : 0.0;          // 9 previous values if rows == 10, else 8
-#pragma unroll
-    for (int j = 1; j < SBR_KLA_HIST - 1; ++j) ksum = ksum + hist[j];
     // AE_OCI = 8/((t1-t0) 1800) 1.32 sum(Kla) td (:70-71), EC_OCI = EC_conc sum(EC) td/((t1-t0) 1000) (:79): one reciprocal
     const double esum = __builtin_fma((double)(c.rows - 2), c.ec_last, c.ec_prev);
     const double aek = (8 * 1.32 * td / 1800) * ksum, eck = (p.EC_conc * td / 1000) * esum, rs = sbr_rcp(c.span);
@@ -595,7 +631,8 @@ SBR_DEV double sbr_draw(const SbrPar& p, double (&x)[SBR_NX], const double (&sx)
     return qw;
 }
 
-SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX]) {
+template <typename H>
+SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX]) {
     const double t_set = p.t_settle * p.t_cycle;
     double sx[10], sx_eff;
     const double xf = sbr_settle(p, x, t_set, sx);
@@ -614,7 +651,7 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
     sbr_rk4<0>(p, x, span * sbr_rcp((double)(n > 0 ? n : 1)), n, kla, 0.0, nold);
-    sbr_hist_push(hist, kla);                         // Kla.append in Sim_idle (:2578)
+    hs.push(kla);                                     // Kla.append in Sim_idle (:2578)
     c.kla_last = kla;
     return qw;
 }
@@ -623,10 +660,10 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_H
 // xa6 is updated to the pre-settle values when the terminal phases run; qw is written only then.
 // OCI = the operating-cost reward (cfg.reward_kind 2) with its running sum(Kla) of the episode's list, ksum: a
 // compile-time variant, so that the default kernels carry none of it.
-template <bool OCI>
-SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KLA_HIST], double (&x)[SBR_NX],
+template <bool OCI, typename H>
+SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX],
                                double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp) {
-    sbr_hist_apply(c, hist);
+    const double kwin = hs.commit_and_window(c);
     double r;
     rp.eqi2 = 0.0; rp.ae = 0.0; rp.ec = 0.0;
     if (OCI) {
@@ -634,7 +671,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KL
         if (c.n_new > 1) ksum = ksum + c.knew[1];
         r = sbr_reward_oci(p, 1, c.kla_last, 0.0, 0.0, 0.0);
     } else {
-        r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, hist, x, rp);     // wave-uniform choice
+        r = p.reward_kind == 1 ? sbr_reward_g2anet(x) : sbr_reward(p, c, kwin, x, rp);     // wave-uniform choice
     }
     t_obs = c.t;
     dn = false;
@@ -643,7 +680,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, double (&hist)[SBR_KL
         if (p.terminal) {
             sbr_take6(x, xa6);
             const double snh_eff = x[10];            // solubles pass the settler unchanged: eff_component[3] (:2642)
-            qw = sbr_terminal(p, c, hist, x);
+            qw = sbr_terminal(p, c, hs, x);
             if (OCI) {
                 ksum = ksum + c.kla_last;            // Sim_idle's Kla.append (:2578)
                 r = sbr_reward_oci(p, 2, c.kla_last, ksum, qw, snh_eff);
