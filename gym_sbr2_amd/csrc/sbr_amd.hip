@@ -16,8 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
-#include <vector>
 
 #ifndef SBR_BLOCK
 #define SBR_BLOCK 256     // threads per workgroup of the stepping kernels: four waves, one per SIMD.  Measured at N = 65536:
@@ -893,7 +893,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     if (ndev <= 0)
         return fail(nullptr, SBR_ERR_NO_DEVICE, "sbr_create: no HIP device visible - this library has no CPU path");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, SBR_ERR_INVALID, "sbr_create: bad device_id");
-    sbr_env* e = new sbr_env();
+    sbr_env* e = new (std::nothrow) sbr_env();
+    if (!e) return fail(nullptr, SBR_ERR_ALLOC, "sbr_create: out of host memory");
     e->n = n_envs; e->device = device_id; e->first_env_id = first_env_id;
     if (cfg) e->cfg = *cfg; else sbr_default_config(&e->cfg);
     const sbr_config& c = e->cfg;
