@@ -993,3 +993,66 @@ def test_results_do_not_depend_on_wave_mates_or_shard_boundaries(G, tables):
     for lo, hi in ((0, cut), (cut, n), (130, 131)):
         xs, cs, ecs = run(lo, hi)
         assert np.array_equal(xs, xa[:, lo:hi]) and np.array_equal(cs, ca[:, lo:hi]) and np.array_equal(ecs, eca[lo:hi]), (lo, hi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("substeps", [5, 20])
+def test_other_substep_counts_against_oracle(G, tables, substeps):
+    """cfg.substeps is a parameter of both the kernels and the oracle (the step h = span / substeps reaches the device as a
+    host-side reciprocal): 90 calls across the anoxic -> aerobic boundary for 5 and 20 substeps per interval, lockstep."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n, calls = 192, 90
+    scen = (np.arange(n) % 8).astype(np.int32)
+    cfg = _capi.default_config(); cfg.substeps = substeps
+    p = O.default_params(); p.substeps = substeps
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64, config=cfg)
+    ora = O.OracleBatch(n, params=p)
+    rnd = np.random.RandomState(substeps).randn(n, 48)
+    obs = _np(env.reset(scenario=scen, rnd=rnd)).copy()
+    assert np.abs(obs - ora.reset(ora.mix(means, stds, scen, rnd))).max() < 1e-10
+    rs = np.random.RandomState(3)
+    for c in range(calls):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)])
+        x, ctrl = env.get_state()
+        ora.load_state(_np(x), _np(ctrl))
+        o, s_, r, d = env.step(torch.from_numpy(a).cuda())
+        oo, os_, orr, od = ora.step(a)
+        x, ctrl = env.get_state()
+        assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6 and np.array_equal(_np(d), od), c
+        assert np.abs(_np(r) - orr).max() < 1e-12 and np.abs(_np(o) - oo).max() < 1e-10
+        assert np.array_equal(_np(ctrl)[_capi.C_T], ora.envs["t"])
+    assert float(_np(ctrl)[_capi.C_T].min()) > 0.0641667            # the run crossed into the aerobic phase
+    env.close()
+
+
+@pytest.mark.gpu
+def test_trace_of_several_envs_and_cycle_env_scenario_draw(G, tables):
+    """Trajectory export for more than one env of a ragged batch (records of the first n_trace envs only, per-env columns),
+    and cfg.random_scenario in the per-cycle env (sbr_cycle_reset draws like sbr_reset)."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n, nt, calls = 100, 37, 50
+    scen = (np.arange(n) % 8).astype(np.int32)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    tr = env.enable_trace(n_envs=nt, capacity=calls)
+    env.reset(seed=2, scenario=scen)
+    rs = np.random.RandomState(8)
+    rew = []
+    for c in range(calls):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)])
+        o, s_, r, d = env.step(torch.from_numpy(a).cuda())
+        rew.append(_np(r).copy())
+    x, ctrl = env.get_state()
+    t = _np(tr)
+    assert t.shape == (calls, _capi.NTRACE, nt) and np.isfinite(t).all()
+    assert np.array_equal(t[:, _capi.TR_REWARD, :], np.array(rew)[:, :nt])
+    assert np.array_equal(t[-1, _capi.TR_X0:_capi.TR_X0 + 14, :], _np(x)[:, :nt]) and np.array_equal(t[-1, _capi.TR_T, :], _np(ctrl)[_capi.C_T, :nt])
+    assert np.allclose(t[:, _capi.TR_R_OCI, :], t[:, _capi.TR_R_AE, :] + t[:, _capi.TR_R_EC, :], rtol=0, atol=1e-15)
+    env.disable_trace(); env.close()
+    cyc = G.SbrEnv2Vec(256, out_dtype=torch.float64, random_scenario=True)
+    cyc.reset(seed=21)
+    sc = O.OracleBatch(256).scenarios(21)
+    want = O.OracleBatch(256).mix(means, stds, sc, O.OracleBatch(256).normals(21))
+    assert len(set(sc.tolist())) == 8 and np.abs(_np(cyc.influent()).T[:, 1:] - want[:, 1:]).max() < 1e-11
+    cyc.close()
