@@ -9,7 +9,8 @@
 //   k_cycle_reset, k_cycle   the per-cycle env SBR-v2: one launch = one whole 12 h cycle (528 control intervals)
 //   k_export, k_import       public <-> internal controller layout
 //   k_stats    wavefront (DPP) reductions of a per-env vector -> {sum,min,max,count}
-//   k_rhs, k_normals  known-answer helpers for the parity tests
+//   k_rhs, k_normals, k_scenarios, k_fill   known-answer helpers for the parity tests, the scenario draw, handle init
+// What bounds them and how the arithmetic is organised for it: sbr_device.h (sbr_rates, sbr_rk4), DESIGN.md sections 3 and 5.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -20,8 +21,8 @@
 #include <string>
 
 #ifndef SBR_BLOCK
-#define SBR_BLOCK 256     // threads per workgroup of the stepping kernels: four waves, one per SIMD.  Measured at N = 65536:
-                          // 64 -> 23.0 us, 128 -> 22.8, 256 -> 22.65 per k_step launch (fewer workgroups to dispatch)
+#define SBR_BLOCK 256     // threads per workgroup of the stepping kernels: four waves, one per SIMD.  Measured at N = 65536
+                          // (round 1): 64 -> 23.0 us, 128 -> 22.8, 256 -> 22.65 per k_step launch (fewer workgroups to dispatch)
 #endif
 #include "sbr_device.h"
 
@@ -331,17 +332,16 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 }
 
 // ------------------------------------------------------------------------------------------- step
-// All loads of a lane are issued up front (they are asynchronous; the first use waits): one exposed memory round
-// trip per launch.  Measured alternatives that were WORSE (profiles/r01_notes.md): loading the Kla history and the
-// bookkeeping rows after the integration (+2.4 us: three serial round trips), and staging obs/state through LDS for
-// coalesced stores (no gain: L2 write-combining already absorbs the 72/60-byte rows).
-// Two builds of the kernel: W = 1 lets the allocator use the whole register file (fastest single wave: batches of up
-// to one wave per SIMD, N <= 65536) and W = 2 keeps two waves resident per SIMD so that the load/store phases of one
-// overlap the arithmetic of the other (measured on MI355X: -4 % at N = 65536, +7 % at 131072, +18 % at 262144).
-// Values that only have to SURVIVE the integration (nine Kla history values, return, packed steps/status/done, the six
-// xdot start values: 17 doubles per lane, 18 with the operating-cost reward's running sum) are parked in LDS, not in
-// VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and the RK4 loop keeps its registers
-// (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at park[(w*NSLOT + j)*64 + l] (conflict-free).
+// All loads of a lane are issued up front, with addresses that depend on nothing loaded (they are asynchronous; the first
+// use waits): ONE exposed memory round trip per launch.  Measured alternatives that were WORSE (profiles/r01_notes.md):
+// loading the Kla history and the bookkeeping rows after the integration (+2.4 us: serial round trips).
+// The template parameter W is the occupancy the register allocator has to leave room for (waves per SIMD); since round 2
+// both instantiations come out at 250 VGPRs, i.e. two waves per SIMD, which batches above 65536 envs use to overlap the
+// memory phases of one wave with the arithmetic of the other (and to issue FMAs at 4.43 instead of 5.19 cycles).
+// Values that only have to SURVIVE the integration (the Kla ring, return, packed steps/status/done, the six xdot start
+// values) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and
+// the RK4 loop keeps its registers (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at
+// park[(w*NSLOT + j)*64 + l] (conflict-free).
 // LDS slots of a lane in k_step: the Kla ring as loaded (physical slot order) in 0..9 and AGAIN in 10..17 (slots 0..7), so
 // that entry i of the logical tail, ring slot (kb + i) mod 10, is simply LDS slot kb + i: one per-lane base address and
 // constant offsets, no wrap arithmetic per read; then return, meta, the six xdot start values (and the OCI running sum).
