@@ -46,9 +46,9 @@ ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
 # float64 operations per RK4 substep, counted in the gfx950 ISA of the two substep loops of k_step (round 2): when no lane of
-# the wave doses carbon 155 FMA x 2 + 112 MUL + 8 ADD + 4 RCP = 434; with dosing 209 x 2 + 124 + 12 + 4 = 558.  The loop only
+# the wave doses carbon 159 FMA x 2 + 104 MUL + 4 ADD + 4 RCP = 430; with dosing 213 x 2 + 116 + 8 + 4 = 554.  The loop only
 # (no PIDs, reward, observations): a LOWER bound of the work per env-step.
-FP64_FLOP_PER_SUBSTEP = {"plain": 434, "dosing": 558}
+FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 554}
 SUBSTEPS = 10
 # vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
 # vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles
@@ -176,7 +176,6 @@ def main():
     import torch
     import torch.distributed as dist
     from gym_sbr2_amd import ShardedSbrOS, _capi
-    from gym_sbr2_amd.sharding import gather_returns
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

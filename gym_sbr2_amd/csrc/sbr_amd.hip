@@ -814,6 +814,7 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.f1a = c.kh / c.muH; p.f1b = c.Ks * (c.kh / c.muH);
     p.f2a = 1.0 / c.kh; p.f2b = c.Koh / c.kh;
     p.f4a = 1.0 / c.muA; p.f4b = c.Knh / c.muA;
+    p.f3a = 1.0 / (c.Koh * c.eta_g); p.f3b = c.Kno / (c.Koh * c.eta_g);
     p.KohEtag = c.Koh * c.eta_g; p.etah_g = c.eta_h / c.eta_g;
     p.bA_bH = c.bA / c.bH; p.n4_45b = p.n4_45 * c.bH; p.n12_45b = p.n12_45 * c.bH; p.n7_45b = p.n7_45 * c.bH;
     p.n9_23 = p.n9_2 / p.n9_3; p.inv_n9_3 = 1.0 / p.n9_3;
@@ -917,8 +918,9 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     if (!(c.tauI_DO != 0) || !(c.tauI_EC != 0) || !(c.cyc_tauI != 0) || !(c.cyc_dt > 0)) bad = "tauI must be non-zero, cyc_dt positive";
     // the rate constants that are folded into the Monod denominators (sbr_rates) must be positive and finite
     if (!(c.muH > 0 && c.muH < 1e300) || !(c.muA > 0 && c.muA < 1e300) || !(c.kh > 0 && c.kh < 1e300) ||
-        !(c.eta_g > 0 && c.eta_g < 1e300) || !(c.bH > 0 && c.bH < 1e300) || !(c.Ya > 0 && c.Ya < 1e300))
-        bad = "muH, muA, kh, eta_g, bH and Ya must be positive";
+        !(c.eta_g > 0 && c.eta_g < 1e300) || !(c.bH > 0 && c.bH < 1e300) || !(c.Ya > 0 && c.Ya < 1e300) ||
+        !(c.Koh > 0 && c.Koh < 1e300))
+        bad = "muH, muA, kh, eta_g, Koh, bH and Ya must be positive";
     if (c.substeps > (1 << 20)) bad = "substeps out of range";
     for (int k = 0; k < 8; ++k) if (!(c.t_ratio[k] > 0)) bad = "t_ratio entries must be positive";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }

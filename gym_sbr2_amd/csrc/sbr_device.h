@@ -50,7 +50,7 @@ struct SbrPar {
     double x0[SBR_NX];
     // kinetics folded into the Monod denominators (sbr_rates): d1 = f1a Ss + f1b = (Ks + Ss) kh/muH,
     // d2 = f2a So + f2b = (Koh + So)/kh, d4 = f4a Snh + f4b = (Knh + Snh)/muA
-    double f1a, f1b, f2a, f2b, f4a, f4b;
+    double f1a, f1b, f2a, f2b, f3a, f3b, f4a, f4b;   // d3 = f3a Sno + f3b = (Kno + Sno)/(eta_g Koh)
     double KohEtag;      // Koh * eta_g
     double etah_g;       // eta_h / eta_g
     // rho4 + rho5 is carried as s45/bH = Xbh + (bA/bH) Xba, Sno's derivative as k/nu9_3: the factors sit in the coefficients
@@ -108,12 +108,13 @@ struct SbrRho { double rho1, rho2, rho3, rho6, s45b; };        // s45b = (rho4 +
 //
 // fp64 VALU issue is the bound of every stepping kernel (one wave per SIMD issues a v_fma_f64 every 5.2 cycles, a
 // v_mul/v_add_f64 every 4.3, v_rcp_f64 costs 16: scripts/probes/fp64_issue.hip), so this function is written for
-// INSTRUCTION COUNT, 51 + one v_rcp_f64 (the first version: 92 + 7):
-//  * the reference's ten quotients need six denominators; all six reciprocals come from ONE v_rcp_f64 of their product,
-//    peeled apart as a tree (pairs first): 5 + 8 multiplications, dependency depth 3 + 3;
-//  * the leading constants of the rates (muH, muA, kh, eta_g) are folded into the denominators on the host - a
+// INSTRUCTION COUNT, 49 + one v_rcp_f64 (the first version: 92 + 7):
+//  * the reference's ten quotients need six denominators; everything comes from ONE v_rcp_f64 of their product, from
+//    which exactly the four quotients the rates use are formed - 1/(d1 d2), 1/(d4 d5), 1/d3, 1/(d2 d6) -: 5 + 7
+//    multiplications, dependency depth 3 + 3;
+//  * the leading constants of the rates (muH, muA, kh, eta_g Koh) are folded into the denominators on the host - a
 //    denominator (K + x)*c costs one FMA instead of one ADD - so that rho1, rho2, rho3, rho7 come out of the
-//    reciprocals already scaled: d1 = (Ks+Ss) kh/muH, d2 = (Koh+So)/kh, d4 = (Knh+Snh)/muA;
+//    reciprocals already scaled: d1 = (Ks+Ss) kh/muH, d2 = (Koh+So)/kh, d3 = (Kno+Sno)/(eta_g Koh), d4 = (Knh+Snh)/muA;
 //  * So/(Koh+So) and Koh/(Koh+So) share 1/d2, which is factored out of the hydrolysis bracket together with 1/d6;
 //    (Xs/Xbh)/(Kx + Xs/Xbh) is Xs/(Kx Xbh + Xs), and rho8 = (Xnd/Xs) rho7 needs no 1/Xs because rho7 carries the factor
 //    Xs (also the continuous extension at Xs -> 0, where the reference evaluates 0/0);
@@ -129,20 +130,21 @@ SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, d
                  snd = a[A_SND], xnd = a[A_XND];
     const double d1 = __builtin_fma(ss, p.f1a, p.f1b);        // (Ks + Ss) kh/muH
     const double d2 = __builtin_fma(so, p.f2a, p.f2b);        // (Koh + So)/kh
-    const double d3 = p.Kno + sno;
+    const double d3 = __builtin_fma(sno, p.f3a, p.f3b);       // (Kno + Sno)/(eta_g Koh)
     const double d4 = __builtin_fma(snh, p.f4a, p.f4b);       // (Knh + Snh)/muA
     const double d5 = p.Koa + so;
     const double d6 = __builtin_fma(p.Kx, xbh, xs);
-    const double A = d1 * d2, B = d4 * d5, Cc = d3 * d6, AB = A * B;
-    const double R = sbr_rcp(AB * Cc);
-    const double rC = R * AB, rAB = R * Cc;
-    const double rA = rAB * B;                                 // muH / ((Ks+Ss)(Koh+So))
-    const double rB = rAB * A;                                 // muA / ((Knh+Snh)(Koa+So))
-    const double rc = rC * d6;                                 // 1/(Kno+Sno)
-    const double rfb = (rC * d3) * (rA * d1);                  // kh / ((Kx Xbh + Xs)(Koh+So))
+    // one reciprocal of d1 d2 d3 d6 (d4 d5), then exactly the four quotients the rates use: 5 + 7 multiplications
+    const double A = d1 * d2, B = d4 * d5, Cc = d3 * d6, AC = A * Cc;
+    const double R = sbr_rcp(AC * B);
+    const double rB = R * AC;                                  // muA / ((Knh+Snh)(Koa+So))
+    const double rAC = R * B;                                  // 1/(d1 d2 d3 d6)
+    const double rA = rAC * Cc;                                // muH / ((Ks+Ss)(Koh+So))
+    const double rc = (rAC * A) * d6;                          // eta_g Koh / (Kno+Sno)
+    const double rfb = rAC * (d1 * d3);                        // 1/(d2 d6) = kh / ((Kx Xbh + Xs)(Koh+So))
     const double G = (ss * xbh) * rA;
     const double rho1 = G * so;                                // muH Ss/(Ks+Ss) So/(Koh+So) Xbh
-    const double kw = p.KohEtag * (sno * rc);                  // eta_g Koh Sno/(Kno+Sno)
+    const double kw = sno * rc;                                // eta_g Koh Sno/(Kno+Sno)
     const double rho2 = G * kw;                                // muH Ss/(Ks+Ss) Koh/(Koh+So) Sno/(Kno+Sno) eta_g Xbh
     const double c7 = (rfb * __builtin_fma(p.etah_g, kw, so)) * xbh;   // rho7/Xs = kh [So + eta_h Koh Sno/(Kno+Sno)] Xbh / (d6 (Koh+So))
     const double rho7 = xs * c7, rho8 = xnd * c7;
