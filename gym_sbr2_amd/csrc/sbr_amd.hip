@@ -461,7 +461,7 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
         SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
         SBR_STAMP(2, false);
-        sbr_run_intervals(p, c, x, a0, a1, x6);
+        sbr_run_intervals<true>(p, c, x, a0, a1, x6);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
         SbrHistLds hs{tail0, kla_before, 0.0, false};
         x6.get(xa6);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
         if (finished) continue;
         double t_obs;
         bool dn;
-        sbr_run_intervals(p, c, x, (double)a0, (double)a1, x6);
+        sbr_run_intervals<false>(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
         SbrHistReg hs{hist};
         const double r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);

@@ -418,26 +418,50 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     c.st_new |= sbr_status_bits(p, x);
 }
 
-// The phase logic of SbrOS.step (:860-1010): four sequential tests on the running time (:860, :896, :931, :963); a call
-// that crosses a phase boundary runs a second interval.  Written as a loop over the four tests so that the interval
-// code exists ONCE in the kernel.  Envs reset together are in lockstep, so the branch is wave-uniform in practice;
-// divergent waves are still correct.
-template <typename X6>
+// The phase logic of SbrOS.step (:860-1010): four sequential `if`s on the running time (:860 anoxic, :896 aerobic, :931
+// anoxic, :963 aerobic), each with its own clipping of the action; a call that crosses a phase boundary runs a second
+// interval (3 times per episode).  A third cannot fire: sbr_create checks that every phase is longer than t_delta.
+// The four conditions are mutually exclusive for a given t, so the first one that fires is phase(t); after its interval t
+// has advanced, and a LATER test fires in the same call exactly when phase(t) has increased.
+// Two equivalent forms, chosen per kernel by measurement (profiles/r02_notes.md, r02_ab_phase_logic.log, r02_ab_loop2.log):
+//  LOOP = true   two passes of "run an interval if phase(t) is past the last one run", so that the interval code exists
+//                ONCE in the kernel (k_step is sensitive to code size: 14.33 us per launch; a loop over the reference's four
+//                tests 14.68; straight-line 14.9);
+//  LOOP = false  straight-line, the second interval behind an unlikely branch (k_rollout: 7.7 us per call against 8.0 - in a
+//                loop the plant is a loop-carried value, ~60 register copies per call).
+// Envs reset together are in lockstep, so the branches are wave-uniform in practice; divergent waves are still correct.
+SBR_DEV int sbr_phase(const SbrPar& p, double t) {
+    return t < p.T3_0 ? 0 : (t <= p.T3_end ? 1 : (t <= p.T4_end ? 2 : (t > p.T4_end ? 3 : -1)));      // -1: t is NaN
+}
+template <bool LOOP, typename X6>
 SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6) {
     a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
     a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
     c.n_new = 0; c.st_new = 0;
+    if (LOOP) {
+        int last = -1;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        const double t = c.t;
-        const bool aerobic = (pass & 1) != 0;
-        const bool fire = pass == 0 ? (t < p.T3_0)
-                        : pass == 1 ? (t >= p.T3_0 && t <= p.T3_end)
-                        : pass == 2 ? (t > p.T3_end && t <= p.T4_end)
-                                    : (t > p.T4_end);
-        if (fire && c.n_new < 2) {
+        for (int it = 0; it < 2; ++it) {
+            const int ph = sbr_phase(p, c.t);
+            if (ph > last) {
+                const bool aerobic = (ph & 1) != 0;
+                if (aerobic) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
+                sbr_interval(p, c, x, xs6, aerobic);
+                last = ph;
+            }
+        }
+    } else {
+        const int ph = sbr_phase(p, c.t);
+        if (ph >= 0) {
+            const bool aerobic = (ph & 1) != 0;
             if (aerobic) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
             sbr_interval(p, c, x, xs6, aerobic);
+            const int ph2 = sbr_phase(p, c.t);
+            if (__builtin_expect(ph2 > ph, 0)) {
+                const bool aerobic2 = (ph2 & 1) != 0;
+                if (aerobic2) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
+                sbr_interval(p, c, x, xs6, aerobic2);
+            }
         }
     }
 }
