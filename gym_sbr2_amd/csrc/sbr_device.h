@@ -223,6 +223,9 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
     sbr_gather(x, a);
     const double v0 = x[0], n0 = x[10] - x[9];                 // V and Snh - Sno at the start
     double v = v0, rv = FLOW ? sbr_rcp(v0) : 0.0;
+    // unrolled by two: the state and the running combination swap registers from one substep to the next, which a rolled
+    // loop pays with nine register copies per substep (288 -> 275 instructions per substep, k_step -0.25 us, rollout -3 %)
+#pragma unroll 2
     for (int s = 0; s < n; ++s) {
         double k[SBR_NA], y[SBR_NA], acc[SBR_NA], y7 = xp, acc7, q = 0.0, qn = 0.0;
         SbrRho o;
