@@ -30,6 +30,9 @@ Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase)
 not counted as steps.  Before the W warm-up steps the same workload runs untimed for PRIME_SECONDS of wall time: the GPU needs
 ~25 ms of sustained work to reach its steady clocks (measured with scripts/probes/clock_ramp.py: 20.95 us per launch in the
 first block, 19.5 us from the fourth on, 21.1 us again after 2 s idle), which a warm-up of a few dozen 20-us steps never gives.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
+The K steps are bracketed by barrier + torch.cuda.synchronize() on both sides; each rank reads its clock right after its own
+closing synchronise (before the closing barrier), and the MAX over ranks is taken: the time until the slowest rank has finished
+its K steps, without the latency of the closing collective itself.
 """
 import argparse
 import json
@@ -125,8 +128,9 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
     t0 = time.perf_counter(); e0.record()
     for k in range(steps):
         one(100 + k)
-    e1.record(); fence()
-    elapsed = time.perf_counter() - t0
+    e1.record(); torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0          # clock read between the closing synchronise and the closing barrier, see main()
+    fence()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
@@ -285,8 +289,9 @@ def main():
     episodes_before = state["episode"]
     t0 = time.perf_counter()
     run(args.steps, record=True)
-    fence()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)                 # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
+    elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
+    fence()                                     # a collective's own latency is not part of the K steps
     if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
