@@ -48,6 +48,7 @@ SYMBOLS = {
     "sbr_version": (C.c_char_p, []),
     "sbr_default_config": (C.c_int, [C.POINTER(SbrConfig)]),
     "sbr_device_count": (C.c_int, []),
+    "sbr_rows_thresholds": (C.c_int, [C.POINTER(SbrConfig), C.POINTER(C.c_double)]),
     "sbr_create": (C.c_int, [_I64, C.c_int, _I64, C.POINTER(SbrConfig), C.POINTER(_VP)]),
     "sbr_destroy": (C.c_int, [_VP]),
     "sbr_last_error": (C.c_char_p, [_VP]),

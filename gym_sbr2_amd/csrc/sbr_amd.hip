@@ -883,6 +883,15 @@ int sbr_default_config(sbr_config* c) {
     return SBR_OK;
 }
 
+int sbr_rows_thresholds(const sbr_config* cfg, double* out2) {
+    if (!out2) return SBR_ERR_INVALID;
+    sbr_config c;
+    if (cfg) c = *cfg; else sbr_default_config(&c);
+    if (!(c.dt > 0)) return SBR_ERR_INVALID;
+    out2[0] = rows_threshold(c.dt, 9); out2[1] = rows_threshold(c.dt, 10);
+    return SBR_OK;
+}
+
 int sbr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -124,6 +124,12 @@ typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for
 const char* sbr_version(void);
 int sbr_default_config(sbr_config* cfg);
 int sbr_device_count(void);          /* HIP devices visible; 0 if none (never throws) */
+/* Host-side helper, no device needed: the reference's control interval has len(t_range) = int(((t + t_delta) - t)/dt) output
+ * rows (gym_SBR_oneshot.py:1339, :1384), 9 or 10 depending on the rounding of (t + t_delta) - t, and the reward's look-back
+ * depends on it.  The kernels decide it with two comparisons: out2[0] / out2[1] = the smallest doubles s for which the IEEE
+ * quotient s/dt reaches 9.0 / 10.0 (rows = 10 iff span >= out2[1], 9 iff out2[0] <= span < out2[1]; any other span takes the
+ * division itself).  cfg NULL = defaults. */
+int sbr_rows_thresholds(const sbr_config* cfg, double* out2);
 
 /* lifetime: replaces SbrOS.__init__ (gym_SBR_oneshot.py:103-166) for N instances.
  * first_env_id: global id of local env 0 (multi-GPU sharding: RNG streams and scenario

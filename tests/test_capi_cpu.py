@@ -102,3 +102,39 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "sbr_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_interval_row_count_thresholds_reproduce_the_ieee_quotient():
+    """Host logic behind len(t_range) = int(((t + t_delta) - t)/dt) (gym_SBR_oneshot.py:1339, :1384): the kernels replace the
+    division by two comparisons against thresholds found on the host.  For every span within +-200 ulp of 9 dt and 10 dt,
+    and for every span the reference's own time recurrence produces over an episode, the classification equals the IEEE
+    quotient truncated, and both row counts occur."""
+    lib = _capi.load()
+    cfg = _capi.default_config()
+    thr = (C.c_double * 2)()
+    assert lib.sbr_rows_thresholds(C.byref(cfg), thr) == 0 and lib.sbr_rows_thresholds(None, thr) == 0
+    t9, t10 = thr[0], thr[1]
+    dt, t_delta = cfg.dt, cfg.t_delta
+
+    def rows_fast(span):
+        return 10 if span >= t10 else (9 if span >= t9 else None)
+    for centre in (9 * dt, 10 * dt):
+        s = centre
+        for _ in range(200):
+            s = np.nextafter(s, 0.0)
+        for _ in range(400):
+            want = int(s / dt)
+            got = rows_fast(s)
+            assert got == want or (got is None and want < 9), (s, got, want)
+            s = np.nextafter(s, 1.0)
+    assert int(np.nextafter(t10, 0.0) / dt) == 9 and int(t10 / dt) == 10 and int(np.nextafter(t9, 0.0) / dt) == 8 and int(t9 / dt) == 9
+    seen, t = set(), cfg.T_fill
+    for _ in range(466):                     # the time recurrence of an episode: t += t_delta in float64
+        t1 = t + t_delta
+        span = t1 - t
+        assert rows_fast(span) == int(span / dt)
+        seen.add(rows_fast(span)); t = t1
+    assert seen == {9, 10}
+    e = golden("sbros_const_2_5")
+    spans = e["iv_t_end"] - e["iv_t_start"]
+    assert [rows_fast(s) for s in spans] == e["iv_n_rows"].tolist()      # the reference's own 466 intervals
