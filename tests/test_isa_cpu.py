@@ -1,0 +1,107 @@
+"""Static checks of the gfx950 ISA that hipcc generates for the stepping kernels (cross-compiled here, no GPU needed):
+the figures DESIGN.md and bench.py quote - float64 operations per RK4 substep, no IEEE division on the ordinary path, no
+scratch, two waves per SIMD - are asserted against the compiler's output, so that they cannot drift from the code."""
+import collections
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+from conftest import ROOT
+
+from gym_sbr2_amd import build as B
+
+K_STEP = "_Z6k_stepIffLi1ELb0EE"          # k_step<float, float, 1, false>: the kernel bench.py times
+K_ROLLOUT = "_Z9k_rolloutILb0EE"
+K_CYCLE = "_Z7k_cycleIffE"
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "sbr_amd.s"
+    flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([B.hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(out), B.SRC], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def kernel_text(asm, symbol):
+    m = re.search(r"^%s[^\n:]*:[^\n]*\n(.*?)\n\.Lfunc_end" % re.escape(symbol), asm, re.S | re.M)
+    assert m, symbol
+    return m.group(1)
+
+
+def instructions(text):
+    out = []
+    for line in text.split("\n"):
+        line = line.split(";")[0].strip()
+        if line and not line.endswith(":") and not line.startswith("."):
+            out.append(line)
+    return out
+
+
+def inner_loops(text):
+    """[(instruction list)] of the innermost loops (backward branches that contain no other backward branch)."""
+    lines = []
+    for raw in text.split("\n"):
+        l = raw.split(";")[0].strip()
+        if l and (l.endswith(":") or not l.startswith(".")):
+            lines.append(l)
+    label = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.match(r"s_(?:cbranch_\w+|branch)\s+(\.LBB\S+)", l)
+        if m and m.group(1) in label and label[m.group(1)] < i:
+            loops.append((label[m.group(1)], i))
+    inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
+    return [[x for x in lines[a:b + 1] if not x.endswith(":")] for a, b in inner]
+
+
+def f64_mix(ins):
+    c = collections.Counter(i.split()[0] for i in ins)
+    return {"fma": c["v_fma_f64"] + c["v_fmac_f64_e32"], "mul": c["v_mul_f64"], "add": c["v_add_f64"], "rcp": c["v_rcp_f64_e32"],
+            "div": c["v_div_fmas_f64"], "lane": c["v_readlane_b32"] + c["v_writelane_b32"], "scratch": sum(v for k, v in c.items() if k.startswith("scratch_"))}
+
+
+def meta(asm, symbol, key):
+    m = re.search(r"\.name:\s+%s\S*\n(?:.*\n){0,20}?\s+\.%s:\s+(\d+)" % (re.escape(symbol), key), asm)
+    if m is None:      # the key may precede .name inside the kernel's metadata map
+        blk = re.search(r"(- \.agpr_count.*?\.name:\s+%s\S*\n.*?\.wavefront_size:\s+\d+)" % re.escape(symbol), asm, re.S)
+        m = re.search(r"\.%s:\s+(\d+)" % key, blk.group(1)) if blk else None
+    assert m, (symbol, key)
+    return int(m.group(1))
+
+
+def test_rk4_substep_loops_have_the_quoted_instruction_mix(asm):
+    import bench
+    loops = inner_loops(kernel_text(asm, K_STEP))
+    rk4 = [f64_mix(l) for l in loops if f64_mix(l)["rcp"] == 8 and f64_mix(l)["fma"] > 250]     # unrolled by two: 8 reciprocals
+    assert len(rk4) >= 2
+    per_substep = sorted({(m["fma"] * 2 + m["mul"] + m["add"] + m["rcp"]) // 2 for m in rk4})
+    # bench.py's roofline.fp64_valu counts exactly these loops (FMA = 2 FLOP)
+    assert per_substep[0] == bench.FP64_FLOP_PER_SUBSTEP["plain"] and per_substep[-1] == bench.FP64_FLOP_PER_SUBSTEP["dosing"], per_substep
+    for l in loops:
+        m = f64_mix(l)
+        if m["rcp"] == 8 and m["fma"] > 250:
+            assert m["div"] == 0 and m["lane"] == 0 and m["scratch"] == 0       # nothing but arithmetic in the hot loops
+            assert len(l) <= 2 * (m["fma"] + m["mul"] + m["add"] + m["rcp"]) // 2 + 12   # <= 6 non-arithmetic instructions per substep
+
+
+def test_k_step_has_no_scratch_no_division_on_the_ordinary_path_and_fits_two_waves_per_simd(asm):
+    ins = instructions(kernel_text(asm, K_STEP))
+    m = f64_mix(ins)
+    assert m["scratch"] == 0
+    assert m["div"] <= 8, m["div"]          # <= 8 (terminal / fallback paths only); measured 3
+    assert meta(asm, K_STEP, "private_segment_fixed_size") == 0
+    assert meta(asm, K_STEP, "vgpr_count") <= 256
+    for k in (K_ROLLOUT, K_CYCLE):
+        assert meta(asm, k, "vgpr_count") <= 256
+
+
+def test_k_step_leading_arguments_are_preloaded(asm):
+    m = re.search(r"\.amdhsa_kernel %s\S*\n(.*?)\.end_amdhsa_kernel" % re.escape(K_STEP), asm, re.S)
+    assert m
+    n = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length\s+(\d+)", m.group(1))
+    assert n and int(n.group(1)) >= 14      # x, ctrl, n, action, obs, state, reward arrive in SGPRs
