@@ -363,7 +363,7 @@ def main():
                    "policy": args.policy,
                    "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
-                   "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (2 if n_local > 98304 else 1)},
+                   "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (64 if n_local <= 49152 else 256)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_unit": traffic_note,

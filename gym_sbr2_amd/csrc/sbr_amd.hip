@@ -335,9 +335,12 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // All loads of a lane are issued up front, with addresses that depend on nothing loaded (they are asynchronous; the first
 // use waits): ONE exposed memory round trip per launch.  Measured alternatives that were WORSE (profiles/r01_notes.md):
 // loading the Kla history and the bookkeeping rows after the integration (+2.4 us: serial round trips).
-// The template parameter W is the occupancy the register allocator has to leave room for (waves per SIMD); since round 2
-// both instantiations come out at 250 VGPRs, i.e. two waves per SIMD, which batches above 65536 envs use to overlap the
-// memory phases of one wave with the arithmetic of the other (and to issue FMAs at 4.43 instead of 5.19 cycles).
+// The template parameter BLK is the workgroup size.  256 threads (four waves, one per SIMD of a CU; register allocation
+// leaves room for two waves per SIMD, which batches above 65536 envs use to overlap the memory phases of one wave with the
+// arithmetic of the other and to issue FMAs at 4.43 instead of 5.19 cycles) is the fastest from ~32768 envs up; below that
+// 64-thread workgroups win - one wave per workgroup spreads a batch over four times as many CUs, each with its own path to
+// memory and its own LDS (profiles/r02_ab_block.log: 1024 .. 16384 envs 12.45 -> 11.6 us per launch, 32768: 12.65 -> 12.1,
+// 49152: 13.0 -> 12.8; 65536: 13.85 against 14.03, so 256 from there on).
 // Values that only have to SURVIVE the integration (the Kla ring, return, packed steps/status/done, the six xdot start
 // values) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and
 // the RK4 loop keeps its registers (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at
@@ -408,8 +411,8 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
 // The first eight arguments (16 dwords) are what the first global loads need; the library is built with
 // -mllvm -amdgpu-kernarg-preload-count=16, so a wave starts with them in SGPRs and issues its loads without waiting for a
 // scalar load of the argument segment (two serial scalar round trips before: n for the bounds test, then the pointers).
-template <typename OutT, typename ActT, int W, bool OCI>
-__global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
+template <typename OutT, typename ActT, int BLK, bool OCI>
+__global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
                                                       const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                       OutT* __restrict__ state, OutT* __restrict__ reward,
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
@@ -418,9 +421,9 @@ __global__ __launch_bounds__(SBR_BLOCK, W) void k_step(double* __restrict__ bx, 
     // wave-major: wave w owns park[w][slot][64], 26 (27) slots x 512 B = 13 KiB; the region is reused for the output
     // transpose (64 float64 observation rows take 9216 B)
     constexpr int NSLOT = SBR_NPARK + (OCI ? 1 : 0);
-    __shared__ __attribute__((aligned(16))) double park[NSLOT * SBR_BLOCK];
+    __shared__ __attribute__((aligned(16))) double park[NSLOT * BLK];
     const uint32_t l = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK;
+    const int64_t i0 = (int64_t)blockIdx.x * BLK;
     if (i0 + l >= b.n) return;
 #ifdef SBR_STAMPS
     if (reinterpret_cast<uintptr_t>(b.stamps) == 1) return;   // diagnostic build: the launch period of an EMPTY k_step = the boundary
@@ -834,16 +837,19 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.rows10_min = rows_threshold(c.dt, 10); p.rows9_min = rows_threshold(c.dt, 9);
 }
 
+#ifndef SBR_SMALL_BATCH
+#define SBR_SMALL_BATCH 49152       // up to this many envs k_step runs in 64-thread workgroups (measured: profiles/r02_ab_block.log)
+#endif
 template <typename OutT, typename ActT, bool OCI>
 static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                           hipStream_t st) {
-    const dim3 grid((unsigned)((e->n + SBR_BLOCK - 1) / SBR_BLOCK));
-    if (e->n > 98304)      // more than 1.5 waves per SIMD on 1024 SIMDs: the two-waves-per-SIMD build wins
-        hipLaunchKernelGGL((k_step<OutT, ActT, 2, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->buf.x, e->buf.ctrl, e->buf.n,
-                           (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
+    if (e->n <= SBR_SMALL_BATCH)
+        hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
+                           e->buf.n, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
-        hipLaunchKernelGGL((k_step<OutT, ActT, 1, OCI>), grid, dim3(SBR_BLOCK), 0, st, e->buf.x, e->buf.ctrl, e->buf.n,
-                           (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
+        hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
+                           e->buf.ctrl, e->buf.n, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par,
+                           e->buf);
 }
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,

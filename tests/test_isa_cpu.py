@@ -12,7 +12,8 @@ from conftest import ROOT
 
 from gym_sbr2_amd import build as B
 
-K_STEP = "_Z6k_stepIffLi1ELb0EE"          # k_step<float, float, 1, false>: the kernel bench.py times
+K_STEP = "_Z6k_stepIffLi256ELb0EE"        # k_step<float, float, 256, false>: the kernel bench.py times
+K_STEP_SMALL = "_Z6k_stepIffLi64ELb0EE"     # the 64-thread-workgroup build used up to 49152 envs
 K_ROLLOUT = "_Z9k_rolloutILb0EE"
 K_CYCLE = "_Z7k_cycleIffE"
 
@@ -98,6 +99,8 @@ def test_k_step_has_no_scratch_no_division_on_the_ordinary_path_and_fits_two_wav
     assert meta(asm, K_STEP, "vgpr_count") <= 256
     for k in (K_ROLLOUT, K_CYCLE):
         assert meta(asm, k, "vgpr_count") <= 256
+    small = f64_mix(instructions(kernel_text(asm, K_STEP_SMALL)))
+    assert small["scratch"] == 0 and small["div"] <= 8 and meta(asm, K_STEP_SMALL, "private_segment_fixed_size") == 0
 
 
 def test_k_step_leading_arguments_are_preloaded(asm):
