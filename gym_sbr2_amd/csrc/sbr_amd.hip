@@ -335,8 +335,8 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // All loads of a lane are issued up front, with addresses that depend on nothing loaded (they are asynchronous; the first
 // use waits): ONE exposed memory round trip per launch.  Measured alternatives that were WORSE (profiles/r01_notes.md):
 // loading the Kla history and the bookkeeping rows after the integration (+2.4 us: serial round trips).
-// The template parameter BLK is the workgroup size.  256 threads (four waves, one per SIMD of a CU; register allocation
-// leaves room for two waves per SIMD, which batches above 65536 envs use to overlap the memory phases of one wave with the
+// The template parameter BLK is the workgroup size.  256 threads (four waves, one per SIMD of a CU; the kernel comes out at
+// ~250 VGPRs - tests/test_isa_cpu.py holds it to <= 256 - i.e. two waves per SIMD, which batches above 65536 envs use to overlap the memory phases of one wave with the
 // arithmetic of the other and to issue FMAs at 4.43 instead of 5.19 cycles) is the fastest from ~32768 envs up; below that
 // 64-thread workgroups win - one wave per workgroup spreads a batch over four times as many CUs, each with its own path to
 // memory and its own LDS (profiles/r02_ab_block.log: 1024 .. 16384 envs 12.45 -> 11.6 us per launch, 32768: 12.65 -> 12.1,
@@ -412,7 +412,7 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
 // -mllvm -amdgpu-kernarg-preload-count=16, so a wave starts with them in SGPRs and issues its loads without waiting for a
 // scalar load of the argument segment (two serial scalar round trips before: n for the bounds test, then the pointers).
 template <typename OutT, typename ActT, int BLK, bool OCI>
-__global__ __launch_bounds__(BLK, BLK == 256 ? 2 : 1) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
+__global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
                                                       const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                       OutT* __restrict__ state, OutT* __restrict__ reward,
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
