@@ -1056,3 +1056,57 @@ def test_trace_of_several_envs_and_cycle_env_scenario_draw(G, tables):
     want = O.OracleBatch(256).mix(means, stds, sc, O.OracleBatch(256).normals(21))
     assert len(set(sc.tolist())) == 8 and np.abs(_np(cyc.influent()).T[:, 1:] - want[:, 1:]).max() < 1e-11
     cyc.close()
+
+
+@pytest.mark.gpu
+def test_waves_with_envs_at_different_points_of_their_episodes(G, tables):
+    """Masked resets put the lanes of one wavefront at different points of their episodes: different phases (some lanes dose
+    carbon while others aerate), different ring positions of the Kla history (the per-lane addressing path of k_step), phase
+    boundaries crossed on different calls, episodes ending on different calls.  300 envs, three staggered groups, every call
+    followed by the oracle free-running (reset with the same influent when the device group is reset)."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 300
+    scen = (4 + np.arange(n) % 4).astype(np.int32)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    ora = O.OracleBatch(n)
+    rnd = np.random.RandomState(11).randn(n, 48)
+    infl = ora.mix(means, stds, scen, rnd)
+    env.reset(scenario=scen, rnd=rnd)
+    ora.reset(infl)
+    group = np.arange(n) % 3
+    rs = np.random.RandomState(12)
+
+    def step_both(c):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)])
+        o, s_, r, d = env.step(torch.from_numpy(a).cuda())
+        oo, os_, orr, od = ora.step(a)
+        assert np.array_equal(_np(d), od), c
+        assert np.abs(_np(r) - orr).max() < 1e-11 and np.abs(_np(o) - oo).max() < 1e-9, c
+        return _np(d)
+
+    def reset_group(g):
+        m = (group == g)
+        env.reset(scenario=scen, rnd=rnd, mask=m.astype(np.uint8))
+        sub = O.OracleBatch(int(m.sum()))
+        sub.reset(infl[m])
+        ora.envs[m] = sub.envs
+
+    for c in range(40):
+        step_both(c)
+    reset_group(1)                     # group 1 restarts 40 calls behind
+    for c in range(40, 130):
+        step_both(c)
+    reset_group(2)                     # group 2 restarts 130 calls behind: anoxic next to the others' aerobic phase
+    done_seen = np.zeros(n, bool)
+    for c in range(130, 520):          # group 0 ends on call 463, group 1 on 40 + 463 = 503, group 2 would on 593
+        done_seen |= step_both(c).astype(bool)
+        if c in (200, 300, 400, 470, 510):
+            x, ctrl = env.get_state()
+            assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6, c
+            assert np.array_equal(_np(ctrl)[_capi.C_T], ora.envs["t"]) and np.array_equal(_np(ctrl)[_capi.C_STEPS], ora.envs["steps"])
+            assert np.abs(_np(ctrl)[_capi.C_KLA_HIST0:_capi.C_KLA_HIST0 + 10].T - ora.envs["kla_hist"]).max() < 1e-9
+    assert done_seen[group == 0].all() and done_seen[group == 1].all() and not done_seen[group == 2].any()
+    x, ctrl = env.get_state()
+    assert np.abs(_np(ctrl)[_capi.C_RETURN] - ora.envs["ret"]).max() < 1e-10
+    env.close()
