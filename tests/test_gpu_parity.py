@@ -1110,3 +1110,31 @@ def test_waves_with_envs_at_different_points_of_their_episodes(G, tables):
     x, ctrl = env.get_state()
     assert np.abs(_np(ctrl)[_capi.C_RETURN] - ora.envs["ret"]).max() < 1e-10
     env.close()
+
+
+@pytest.mark.gpu
+def test_output_rows_to_misaligned_destinations(G):
+    """Full wavefronts write their 64 observation / state rows as one contiguous block with 16-byte stores when the
+    destination is 16-byte aligned; any other alignment (a caller's tensor view) takes the per-element form.  Same values."""
+    import ctypes as C
+    n = 256
+    scen = (np.arange(n) % 8).astype(np.int32)
+    a = torch.rand(n, 2, device="cuda") * torch.tensor([2.5, 15.0], device="cuda")
+    outs = []
+    for shift in (0, 1, 2, 3):                       # floats of offset: 0 = aligned, 1..3 = 4, 8, 12 bytes off
+        env = G.SbrOSVec(n)
+        env.reset(seed=4, scenario=scen)
+        obs = torch.full((n * 18 + 8,), -7.0, device="cuda"); st = torch.full((n * 15 + 8,), -7.0, device="cuda")
+        for _ in range(3):
+            rc = env.lib.sbr_step(env._h, C.c_void_p(a.data_ptr()), C.c_void_p(obs.data_ptr() + 4 * shift),
+                                  C.c_void_p(st.data_ptr() + 4 * shift), C.c_void_p(env.reward.data_ptr()),
+                                  C.c_void_p(env.done.data_ptr()), None)
+            assert rc == 0
+        torch.cuda.synchronize()
+        o, s_ = _np(obs), _np(st)
+        assert (o[:shift] == -7).all() and (o[shift + n * 18:] == -7).all() and (s_[:shift] == -7).all() and (s_[shift + n * 15:] == -7).all()
+        outs.append((o[shift:shift + n * 18].copy(), s_[shift:shift + n * 15].copy()))
+        env.close()
+    for o, s_ in outs[1:]:
+        assert np.array_equal(o, outs[0][0]) and np.array_equal(s_, outs[0][1])
+    assert np.isfinite(outs[0][0]).all() and not (outs[0][0] == -7).any()
