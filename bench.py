@@ -124,8 +124,9 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
         torch.cuda.synchronize(dev)
     for k in range(max(1, min(args.warmup, 3))):
         one(k)
-    fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()                    # created and first used outside the timed region
+    fence()
     t0 = time.perf_counter(); e0.record()
     for k in range(steps):
         one(100 + k)
@@ -283,13 +284,22 @@ def main():
     if state["in_episode"] == CALLS_PER_EPISODE:              # warm-up and timing start at the first call of an episode
         end_of_episode()
         reset()
-    run(args.warmup, record=False)
-    # HIP events for the device time of the step launches, created now so that the timed region contains the workload only
-    event_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps // CALLS_PER_EPISODE + 3))]
+    # HIP events for the device time of the step launches.  torch creates an event at its first record(), and the first
+    # timed record of a process costs 30-45 us on top (scripts/probes/sync_wait.py, profiles/r02_sync_wait.log): the warm-up
+    # steps go through the same recording code path and every event of the pool is recorded once, so that the timed region
+    # contains the workload only - with --steps 20 that harness cost was 12 % of the region.
+    event_pool = [torch.cuda.Event(enable_timing=True)
+                  for _ in range(2 * (args.steps // CALLS_PER_EPISODE + args.warmup // CALLS_PER_EPISODE + 6))]
+    for ev in event_pool:
+        ev.record()
+    run(args.warmup, record=True)
+    seg_events.clear()
+    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0)
     fence()
     episodes_before = state["episode"]
     t0 = time.perf_counter()
     run(args.steps, record=True)
+    t_issued = time.perf_counter()              # (diagnostic) the host has issued every launch of the region
     torch.cuda.synchronize(dev)                 # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
     elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
     fence()                                     # a collective's own latency is not part of the K steps
@@ -370,7 +380,7 @@ def main():
                      "algorithmic_bytes_per_launch": n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP,
                      "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                      "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
-                     "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms,
+                     "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
                                          "host_in_reset_issue": acct["reset_issue_ms"]},
                      "fp64_valu": fp64,

@@ -26,6 +26,10 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# the handle of torch's current stream on a device: torch's own fast accessor (an int, no Stream object) where it exists
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 class SbrOSVec:
     """N SBROS-v1 environments on one GPU.
 
@@ -69,14 +73,36 @@ class SbrOSVec:
         _capi.check(self.lib.sbr_set_influent_tables(self._h, means.ctypes.data_as(C.c_void_p),
                                                      stds.ctypes.data_as(C.c_void_p)), self._h)
         n, dev = self.num_envs, self.device
+        self._ashape = (n, 2)
+        self._sbr_step = self.lib.sbr_step
+        self._outs = [None] * 4
+        self._step_out = None
         self.obs = torch.empty((n, _capi.NOBS), dtype=out_dtype, device=dev)
         self.state = torch.empty((n, _capi.NSTATE), dtype=out_dtype, device=dev)
         self.reward = torch.empty((n,), dtype=out_dtype, device=dev)
         self.done = torch.empty((n,), dtype=torch.uint8, device=dev)
 
+    # The output buffers step() and reset() write.  They may be replaced by the caller (same shape, dtype and device, e.g. a
+    # slice of a rollout buffer); their addresses are converted once here, so that the host side of a step is ~5 us of Python
+    # (scripts/gpu_host_overhead.py).
+    def _set_out(self, k, t):
+        shape, dtype = (((self.num_envs, _capi.NOBS), self.out_dtype), ((self.num_envs, _capi.NSTATE), self.out_dtype),
+                        ((self.num_envs,), self.out_dtype), ((self.num_envs,), torch.uint8))[k]
+        if not (isinstance(t, torch.Tensor) and t.shape == shape and t.dtype == dtype and t.device == self.device
+                and t.is_contiguous()):
+            raise ValueError("output buffer %d must be a contiguous %s tensor of shape %s on %s" % (k, dtype, shape, self.device))
+        self._outs[k] = t
+        if all(o is not None for o in self._outs):
+            self._step_out = tuple(C.c_void_p(o.data_ptr()) for o in self._outs)
+
+    obs = property(lambda self: self._outs[0], lambda self, t: self._set_out(0, t))
+    state = property(lambda self: self._outs[1], lambda self, t: self._set_out(1, t))
+    reward = property(lambda self: self._outs[2], lambda self, t: self._set_out(2, t))
+    done = property(lambda self: self._outs[3], lambda self, t: self._set_out(3, t))
+
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(_raw_stream(self.device.index))
 
     def _dev(self, a, dtype, shape):
         if a is None:
@@ -116,13 +142,15 @@ class SbrOSVec:
 
     def step(self, action):
         a = action if (isinstance(action, torch.Tensor) and action.dtype == self.action_dtype and action.is_contiguous()
-                       and action.device == self.device) else self._dev(action, self.action_dtype, (self.num_envs, 2))
-        if tuple(a.shape) != (self.num_envs, 2):
+                       and action.device == self.device) else self._dev(action, self.action_dtype, self._ashape)
+        if a.shape != self._ashape:
             raise ValueError("action must have shape [N,2]")
-        _capi.check(self.lib.sbr_step(self._h, _ptr(a), _ptr(self.obs), _ptr(self.state), _ptr(self.reward),
-                                      _ptr(self.done), self._stream()), self._h)
+        o, s, r, d = self._step_out
+        rc = self._sbr_step(self._h, a.data_ptr(), o, s, r, d, _raw_stream(self.device.index))
+        if rc:
+            _capi.check(rc, self._h)
         self._keep_a = a
-        return self.obs, self.state, self.reward, self.done
+        return tuple(self._outs)
 
     def enable_host_io(self):
         """Small batches driven from the host (the reference-shaped single env): allocate PINNED host buffers for the action

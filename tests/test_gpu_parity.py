@@ -373,6 +373,10 @@ def test_ragged_batch_sizes(G, tables, n):
     ora = O.OracleBatch(n)
     guard = torch.full((n + 64, 18), -7.0, device="cuda")          # obs buffer with a canary tail
     env.obs = guard[:n]
+    for bad in (guard[:n + 1], guard[:n].double(), guard[:n].cpu(), guard[:n, ::2]):     # replaced output buffers are validated
+        with pytest.raises(ValueError):
+            env.obs = bad
+    assert env.obs.data_ptr() == guard.data_ptr()
     obs = _np(env.reset(scenario=scen, rnd=z)); oobs = ora.reset(ora.mix(means, stds, scen, z))
     assert np.abs(obs - oobs).max() < 1e-5 and bool((guard[n:] == -7.0).all())
     for c in range(70):
