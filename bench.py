@@ -32,7 +32,10 @@ not counted as steps.  Before the W warm-up steps the same workload runs untimed
 first block, 19.5 us from the fourth on, 21.1 us again after 2 s idle), which a warm-up of a few dozen 20-us steps never gives.  `value` = (envs of all ranks) * K / (max over ranks of the wall time of the K steps).
 The K steps are bracketed by barrier + torch.cuda.synchronize() on both sides; each rank reads its clock right after its own
 closing synchronise (before the closing barrier), and the MAX over ranks is taken: the time until the slowest rank has finished
-its K steps, without the latency of the closing collective itself.
+its K steps, without the latency of the closing collective itself.  The opening bracket is synchronise, barrier, the LAST of the
+W warm-up steps, synchronise: the first event record and the first launch that follow an RCCL collective cost the host 30-45 us
+each instead of 4-5 (measured with one rank, profiles/r02_notes.md), a cost of the harness's barrier that a 20-step region
+(285 us of kernels) would otherwise carry as 70-80 us; ranks therefore start within one step (14 us) of each other.
 """
 import argparse
 import json
@@ -292,10 +295,15 @@ def main():
                   for _ in range(2 * (args.steps // CALLS_PER_EPISODE + args.warmup // CALLS_PER_EPISODE + 6))]
     for ev in event_pool:
         ev.record()
-    run(args.warmup, record=True)
+    run(max(args.warmup - 1, 0), record=True)
+    # opening bracket: synchronise, barrier, the last warm-up step, synchronise (see the module docstring)
+    torch.cuda.synchronize(dev)
+    if world > 1 or force_dist:
+        dist.barrier()
+    run(min(args.warmup, 1), record=True)
+    torch.cuda.synchronize(dev)
     seg_events.clear()
     acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0)
-    fence()
     episodes_before = state["episode"]
     t0 = time.perf_counter()
     run(args.steps, record=True)
@@ -370,6 +378,7 @@ def main():
         "config": {"workload": workload,
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
                    "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
+                   "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",
                    "policy": args.policy,
                    "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
