@@ -38,6 +38,7 @@ each instead of 4-5 (measured with one rank, profiles/r02_notes.md), a cost of t
 (285 us of kernels) would otherwise carry as 70-80 us; ranks therefore start within one step (14 us) of each other.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -296,6 +297,7 @@ def main():
     for ev in event_pool:
         ev.record()
     run(max(args.warmup - 1, 0), record=True)
+    gc.collect(); gc.disable()                  # no collector pause of the host inside a region that may be 300 us long
     # opening bracket: synchronise, barrier, the last warm-up step, synchronise (see the module docstring)
     torch.cuda.synchronize(dev)
     if world > 1 or force_dist:
@@ -311,6 +313,7 @@ def main():
     torch.cuda.synchronize(dev)                 # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
     elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
     fence()                                     # a collective's own latency is not part of the K steps
+    gc.enable()
     if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
