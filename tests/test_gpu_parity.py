@@ -1142,3 +1142,32 @@ def test_output_rows_to_misaligned_destinations(G):
     for o, s_ in outs[1:]:
         assert np.array_equal(o, outs[0][0]) and np.array_equal(s_, outs[0][1])
     assert np.isfinite(outs[0][0]).all() and not (outs[0][0] == -7).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_dist", [False, True])
+def test_bench_line_contract(force_dist):
+    """bench.py as the driver runs it (`--gpus 1 --steps 20 --warmup 5`), in its own process; with force_dist the process group,
+    the barrier of the bracket and the all-gather run over RCCL with one rank (what every rank of an N > 1 run executes).
+    Checks the ONE JSON line: the contract's keys, value = envs * K / wall, the event-timed launch inside the wall time."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, SBR_BENCH_FORCE_DIST="1" if force_dist else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 65536 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    t = r["timed_region_ms"]
+    assert r["launches_timed"] == 20 and abs(t["step_kernels_device"] - 20 * r["avg_launch_us"] * 1e-3) < 1e-9
+    assert t["step_kernels_device"] <= t["wall"] and t["host_issue"] <= t["wall"]
+    assert 8.0 < r["avg_launch_us"] < 40.0 and d["value"] > 1e9            # sanity: the order of magnitude of this kernel
