@@ -245,8 +245,9 @@ SBR_DEV void influent_lane(const double* lds, bool need_tables, int s, const dou
                 for (int j = 0; j < 13; ++j) acc[j] = acc[j] + (mu[j * SBR_NSAMP + k] + sd[j * SBR_NSAMP + k] * z[u]) * q;
             }
         }
+        const double rsq = sbr_rcp(sq);                               // one reciprocal for the 13 flow-weighted means (1 ulp each)
 #pragma unroll
-        for (int j = 0; j < 13; ++j) ld[1 + j] = acc[j] / sq;
+        for (int j = 0; j < 13; ++j) ld[1 + j] = acc[j] * rsq;
     } else {
 #pragma unroll
         for (int j = 1; j < SBR_NX; ++j) ld[j] = influent[i * SBR_NX + j];
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     if (CARRY) {
         load_x(b, i0, l, x0);
         iv = x0[0]; qin = p.WV - iv;
-        ld[0] = qin / p.T_fill;
+        ld[0] = qin * p.inv_T_fill;
     } else {
 #pragma unroll
         for (int j = 0; j < SBR_NX; ++j) x0[j] = p.x0[j];
@@ -323,8 +324,9 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     CTRL(R_KSUM) = ksum;
     if (obs) {   // volume blend of influent and post-fill state, :346-361
         double xr[SBR_NX];
+        const double rwv = sbr_rcp(qin + iv);
 #pragma unroll
-        for (int j = 0; j < SBR_NX; ++j) xr[j] = (qin * ld[j] + x[j] * iv) / (qin + iv);
+        for (int j = 0; j < SBR_NX; ++j) xr[j] = (qin * ld[j] + x[j] * iv) * rwv;
         double x06[SBR_NXD];
         sbr_take6(x0, x06);
         sbr_write_obs<OutT>(obs + i * SBR_NOBS, 1, c.t, xr, x06, x);
@@ -492,11 +494,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
             hs.tail(c, hist);
             store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
             CTRL(R_QW) = qw;
-        } else if (ring_uniform) {
-            st_out(&CTRL(R_RING0 + kb_u), c.knew[0]);
+        } else if (ring_uniform) {                  // n_new == 0: no interval ran (t injected as NaN), the list is unchanged
+            if (c.n_new > 0) st_out(&CTRL(R_RING0 + kb_u), c.knew[0]);
             if (c.n_new > 1) st_out(&CTRL(R_RING0 + ring_wrap(kb_u + 1)), c.knew[1]);
         } else {
-            CTRL(R_RING0 + kb) = c.knew[0];
+            if (c.n_new > 0) CTRL(R_RING0 + kb) = c.knew[0];
             if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
         }
         meta_unpack(my[(SBR_RING2 + 1) * 64], steps, status, was_done);
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
     double x[SBR_NX], xa6[SBR_NXD], hist[SBR_KLA_HIST];
     SbrCtl c;
+    // x6 and the ten Kla values stay in registers: capped at 256 VGPRs for two waves per SIMD the compiler spills six
+    // loop-invariant doubles (52 B per lane), reloaded once per call outside the RK4 loops.  Parking x6, or x6 and the history,
+    // in LDS instead removes the scratch (251 VGPRs) and is 1 - 2 % SLOWER (7.57 / 7.65 against 7.50 us per call at 65536 envs,
+    // profiles/r03_ab_rollout_scratch.log); without the cap (268 VGPRs) it is 7 % slower at 131072 envs (round 2).
     SbrX6Reg x6;
     SbrRewardParts rp;
     load_x(b, i0, l, x);
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_cycle(SbrPar p, SbrBuf b, cons
     load_x(b, i0, l, x);
 #pragma unroll
     for (int j = 0; j < SBR_NX; ++j) ld[j] = INFL(j);
-    ld[0] = (p.WV - x[0]) / p.t_ph[0];                                // Qin / (t_cycle * t_ratio[0]), gym_SBR_env2.py:144
+    ld[0] = (p.WV - x[0]) * p.inv_t_ph0;                              // Qin / (t_cycle * t_ratio[0]), gym_SBR_env2.py:144 (host reciprocal: 1 ulp)
     const int st0 = sbr_status_bits(p, x);
     const double r = sbr_cycle_env(p, x, ld, (double)action[3 * i], (double)action[3 * i + 1], (double)action[3 * i + 2], o3,
                                    diag ? diag + i * SBR_NCYC_DIAG : nullptr, 1);
@@ -835,6 +841,27 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
         p.inv_ec_max = 1.0 / (c.EC_conc * (0.0005 * 11) * td / ((td * 11) * 1000));
     }
     p.rows10_min = rows_threshold(c.dt, 10); p.rows9_min = rows_threshold(c.dt, 9);
+    {   // SBR-v2 phase schedule, with the reference's own operations (SBR_model_FB.py:30-258: t_start = t_end + t_delta,
+        // t_end = t_start + t_phs; sub_phases_FB.py:183-184: n2 = int((t_end - t_start)/(t_delta*10)), numpy.linspace's step)
+        const double t_delta = 0.002 / 24;                         // gym_SBR_env2.py:34
+        double t_start = 0.0, t_end = 0.0 + p.t_ph[0];
+        int slot = 0;
+        for (int ph = 0; ph < 8; ++ph) {
+            if (ph > 0) { t_start = t_end + t_delta; t_end = t_start + p.t_ph[ph]; }
+            if (ph == 5) { p.cyc_tset = t_end - t_start; continue; }      // settle
+            if (ph == 6) continue;                                         // draw
+            int n2 = (int)((t_end - t_start) / (t_delta * 10));
+            n2 = n2 < 2 ? 2 : (n2 > 100000 ? 100000 : n2);                 // every wave terminates
+            p.cyc_t0[slot] = t_start; p.cyc_t1[slot] = t_end; p.cyc_n2[slot] = n2;
+            p.cyc_step[slot] = (t_end - t_start) / (double)(n2 - 1);
+            p.cyc_inv_ntd[slot] = 1.0 / ((double)(n2 - 1) * t_delta);      // module_reward.py: .../(len(Kla) * t_delta)
+            p.cyc_inv_n[slot] = 1.0 / (double)(n2 - 1);
+            ++slot;
+        }
+        p.inv_t_ph0 = 1.0 / p.t_ph[0];
+        p.sosat_k = c.So_sat / (1.8 * 1000);
+        p.inv_T_fill = 1.0 / c.T_fill;
+    }
 }
 
 #ifndef SBR_SMALL_BATCH

@@ -65,6 +65,15 @@ struct SbrPar {
     // rows9_min <= span < rows10_min: the smallest doubles whose IEEE quotient by dt reaches 10.0 / 9.0 (found on the
     // host by stepping through neighbouring doubles), so the common case costs two comparisons and stays exact
     double rows10_min, rows9_min;
+    // per-cycle env: the schedule of its six PID-controlled phases (fill, 2..5, idle) is wave-uniform, so everything the
+    // reference derives from it with a division - n2 = int((t_end - t_start)/(10 t_delta)), linspace's step, the reward's
+    // 1/(n td) - is taken once on the host with the reference's own IEEE operations (SBR_model_FB.py:18-27, sub_phases_FB.py:183-184)
+    double cyc_t0[6], cyc_t1[6], cyc_step[6], cyc_inv_ntd[6], cyc_inv_n[6];
+    double cyc_tset;         // length of the settling phase as the reference forms it (t_end - t_start)
+    double inv_t_ph0;        // 1 / t_ph[0]
+    double sosat_k;          // So_sat / (1.8 * 1000)
+    double inv_T_fill;
+    int32_t cyc_n2[6];
     int32_t substeps, terminal, fill_rows, reward_kind, random_scenario;
 };
 
@@ -441,6 +450,7 @@ SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], 
     a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
     a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
     c.n_new = 0; c.st_new = 0;
+    c.knew[0] = c.kla_last; c.knew[1] = c.kla_last;      // defined even if no interval runs (t injected as NaN: sbr_phase = -1)
     if (LOOP) {
         int last = -1;
 #pragma unroll 1
@@ -696,7 +706,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
     double r;
     rp.eqi2 = 0.0; rp.ae = 0.0; rp.ec = 0.0;
     if (OCI) {
-        ksum = ksum + c.knew[0];
+        if (c.n_new > 0) ksum = ksum + c.knew[0];
         if (c.n_new > 1) ksum = ksum + c.knew[1];
         r = sbr_reward_oci(p, 1, c.kla_last, 0.0, 0.0, 0.0);
     } else {
@@ -727,13 +737,10 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
 // controlled (clamped) Kla of interval 0 as bias (:219,:243); the integral restarts in every phase.  t_start/t_end
 // are wave-uniform.  Returns the last Kla; ksum = sum(Kla), n_iv = number of intervals.
 template <bool FILL>
-SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], double t_start, double t_end, double sp, double kla_in,
-                               const double (&ld)[SBR_NX], double& ksum, int& n_iv) {
-    const double t_delta = 0.002 / 24;                           // gym_SBR_env2.py:34
-    int n2 = (int)((t_end - t_start) / (t_delta * 10));
-    n2 = n2 < 2 ? 2 : (n2 > 100000 ? 100000 : n2);               // every wave terminates
-    n_iv = n2 - 1;
-    const double step = (t_end - t_start) / (double)(n2 - 1);    // numpy.linspace: i*step + start, last = stop
+SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, double sp, double kla_in,
+                               const double (&ld)[SBR_NX], double& ksum) {
+    const double t_start = p.cyc_t0[ph], t_end = p.cyc_t1[ph], step = p.cyc_step[ph];   // numpy.linspace: i*step + start, last = stop
+    const int n2 = p.cyc_n2[ph], n_iv = n2 - 1;                  // host-clamped to [2, 100000]: every wave terminates
     double so = x[8], so_prev = x[8], ie = 0.0, bias = kla_in, k = kla_in, sum = 0.0;
     for (int i = 0; i < n_iv; ++i) {
         const double g0 = (double)i * step + t_start;
@@ -758,34 +765,26 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], double t_st
 // obs3 = [Qeff, COD_eff, Snh_eff/30]; diag (SBR_NCYC_DIAG doubles) may be nullptr.
 SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double (&ld)[SBR_NX], double a0, double a1, double a2,
                              double (&obs3)[3], double* diag, int diag_stride) {
-    const double t_delta = 0.002 / 24;
     a0 = a0 < 0.0 ? 0.0 : (a0 > 1.0 ? 1.0 : a0); a1 = a1 < 0.0 ? 0.0 : (a1 > 1.0 ? 1.0 : a1);
     a2 = a2 < 0.0 ? 0.0 : (a2 > 1.0 ? 1.0 : a2);
     const double sp3 = a0 * 8, sp5 = a1 * 8, sp8 = a2 * 8;      // DO_setpoints[2], [4], [7]  (:184-186)
     const double qin = p.WV - x[0];
     double ks1, ks2, ks3, ks4, ks5, ks8;
-    int n1, n2, n3, n4, n5, n8;
-    double t_start = 0.0, t_end = 0.0 + p.t_ph[0];
-    double kl = sbr_cycle_phase<true>(p, x, t_start, t_end, 0.0, 0.0, ld, ks1, n1);
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[1];
-    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, 0.0, kl, ld, ks2, n2);
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[2];
-    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, sp3, kl, ld, ks3, n3);
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[3];
-    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, 0.0, kl, ld, ks4, n4);
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[4];
-    kl = sbr_cycle_phase<false>(p, x, t_start, t_end, sp5, kl, ld, ks5, n5);
+    // phases 1..5 (fill, anoxic, aerobic, anoxic, aerobic): schedule indices 0..4; the aerated idle is index 5
+    double kl = sbr_cycle_phase<true>(p, x, 0, 0.0, 0.0, ld, ks1);
+    kl = sbr_cycle_phase<false>(p, x, 1, 0.0, kl, ld, ks2);
+    kl = sbr_cycle_phase<false>(p, x, 2, sp3, kl, ld, ks3);
+    kl = sbr_cycle_phase<false>(p, x, 3, 0.0, kl, ld, ks4);
+    kl = sbr_cycle_phase<false>(p, x, 4, sp5, kl, ld, ks5);
     // settle
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[5];
     double sx[10], sx_eff;
-    const double xf = sbr_settle(p, x, t_end - t_start, sx);
+    const double xf = sbr_settle(p, x, p.cyc_tset, sx);
     // draw; the effluent composition (cal_eq, sub_phases_FB.py:860-915) uses the PRE-draw state with its particulates
-    // scaled by the sludge carried out
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[6];
+    // scaled by the sludge carried out: one reciprocal of Xf for the five of them (1 ulp; the reference divides five times)
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
     const double qw = sbr_draw(p, x, sx, xf, sx_eff);
-    const double exi = xi * (1 / 0.75) * sx_eff / xf, exs = xs * (1 / 0.75) * sx_eff / xf, exbh = xbh * (1 / 0.75) * sx_eff / xf;
-    const double exba = xba * (1 / 0.75) * sx_eff / xf, exp_ = xp * (1 / 0.75) * sx_eff / xf;
+    const double carry = ((1 / 0.75) * sx_eff) * sbr_rcp(xf);
+    const double exi = xi * carry, exs = xs * carry, exbh = xbh * carry, exba = xba * carry, exp_ = xp * carry;
     const double snkj = x[10] + x[11] + x[12] + 0.08 * (exbh + exba) + 0.06 * (exp_ + exi);
     const double ntot = x[9] + snkj;
     const double ss_ = 0.75 * (exs + exi + exbh + exba + exp_);
@@ -794,22 +793,21 @@ SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double 
     const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
     const double snh_eff = x[10], sno_eff = x[9];
     // aerated idle from the drawn reactor, bias = last Kla of phase 5 (SBR_model_FB.py:258)
-    t_start = t_end + t_delta; t_end = t_start + p.t_ph[7];
-    sbr_cycle_phase<false>(p, x, t_start, t_end, sp8, kl, ld, ks8, n8);
-    // reward
+    sbr_cycle_phase<false>(p, x, 5, sp8, kl, ld, ks8);
+    // reward (module_reward.py:4-51): AE_k = 1.32 sum(Kla) td / (n td), the quotient by the wave-uniform n td folded on the host
     const double td = 0.002 / 24;
-    const double ae3 = 1.32 * ks3 * td / ((double)n3 * td), ae5 = 1.32 * ks5 * td / ((double)n5 * td);
-    const double ae8 = (1.32 - qw) * ks8 * td / ((double)n8 * td);
-    const double ae = p.So_sat / (1.8 * 1000) * (ae3 + ae5 + ae8);
+    const double ae3 = (1.32 * ks3 * td) * p.cyc_inv_ntd[2], ae5 = (1.32 * ks5 * td) * p.cyc_inv_ntd[4];
+    const double ae8 = ((1.32 - qw) * ks8 * td) * p.cyc_inv_ntd[5];
+    const double ae = p.sosat_k * (ae3 + ae5 + ae8);
     const double pe = (0.004 * qin + 0.05 * qw + 0.004 * p.Qeff);
     const double me = 0.005 * 1.32 * 24 + 0.005 * 1.32 * 24;
     const double oci = ae + pe + me;
-    obs3[0] = p.Qeff; obs3[1] = cod; obs3[2] = snh_eff / 30;
+    obs3[0] = p.Qeff; obs3[1] = cod; obs3[2] = snh_eff * (1.0 / 30);
     if (diag) {
         const int st = diag_stride;
         diag[0 * st] = qw; diag[1 * st] = eqi; diag[2 * st] = oci; diag[3 * st] = ntot; diag[4 * st] = cod; diag[5 * st] = snh_eff;
-        diag[6 * st] = bod5; diag[7 * st] = sno_eff; diag[8 * st] = ks3 / (double)n3; diag[9 * st] = ks5 / (double)n5;
-        diag[10 * st] = ks8 / (double)n8; diag[11 * st] = xf;
+        diag[6 * st] = bod5; diag[7 * st] = sno_eff; diag[8 * st] = ks3 * p.cyc_inv_n[2]; diag[9 * st] = ks5 * p.cyc_inv_n[4];
+        diag[10 * st] = ks8 * p.cyc_inv_n[5]; diag[11 * st] = xf;
     }
     return (5 - oci) + (snh_eff < 4 ? 0.0 : -20.0);
 }

@@ -16,6 +16,9 @@ K_STEP = "_Z6k_stepIffLi256ELb0EE"        # k_step<float, float, 256, false>: th
 K_STEP_SMALL = "_Z6k_stepIffLi64ELb0EE"     # the 64-thread-workgroup build used up to 49152 envs
 K_ROLLOUT = "_Z9k_rolloutILb0EE"
 K_CYCLE = "_Z7k_cycleIffE"
+K_RESET = "_Z7k_resetIfLb0EE"
+K_RESET_CARRY = "_Z7k_resetIfLb1EE"
+K_CYCLE_RESET = "_Z13k_cycle_resetIfLb0EE"
 
 
 @pytest.fixture(scope="module")
@@ -108,3 +111,20 @@ def test_k_step_leading_arguments_are_preloaded(asm):
     assert m
     n = re.search(r"\.amdhsa_user_sgpr_kernarg_preload_length\s+(\d+)", m.group(1))
     assert n and int(n.group(1)) >= 14      # x, ctrl, n, action, obs, state, reward arrive in SGPRs
+
+
+def test_secondary_kernels_carry_no_ieee_divisions(asm):
+    """the k_step recipe applied to the per-cycle kernel and the resets.  Wave-uniform quotients (phase
+    schedule, 1/(n td), So_sat/1800) are taken on the host with the reference's own operations, per-lane ones go through
+    ONE reciprocal (the 13 flow-weighted influent means, the five effluent particulates, the reset observation's blend)."""
+    assert f64_mix(instructions(kernel_text(asm, K_CYCLE)))["div"] <= 6           # measured 0 (round 2: 26)
+    for k in (K_RESET, K_RESET_CARRY):
+        assert f64_mix(instructions(kernel_text(asm, k)))["div"] <= 4, k         # measured 0 (round 2: 19 / 20)
+    assert f64_mix(instructions(kernel_text(asm, K_CYCLE_RESET)))["div"] <= 4     # measured 2 (round 2: 15)
+    # the fused rollout keeps its 52 B of spilled loop invariants on purpose (profiles/r03_ab_rollout_scratch.log): they are
+    # reloaded outside the RK4 loops, which must stay clean
+    for l in inner_loops(kernel_text(asm, K_ROLLOUT)):
+        m = f64_mix(l)
+        if m["rcp"] >= 4 and m["fma"] > 100:
+            assert m["scratch"] == 0 and m["div"] == 0
+    assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") <= 64
