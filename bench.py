@@ -10,10 +10,15 @@ A "step" is one sbr_step() launch over this rank's batch: every env advances one
 phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
     config2 (default)  65536 envs per GPU, stochastic influent (Philox normals drawn on the device), per-call random float32
                        set-points already resident in HBM, per-step API, RK4 h = dt.  With N > 1 GPUs the envs are sharded by
-                       global id through gym_sbr2_amd.ShardedSbrOS (the class the sharding tests cover) with one RCCL all-gather
-                       of the episode returns per episode inside the timed region: configs[3]'s shape at 65536 envs per GPU
-                       (per-GPU work fixed => weak scaling; 8 GPUs = 524288 envs = 2 x configs[3]'s 262144;
-                       `--envs-per-gpu 32768` gives configs[3] itself).
+                       global id through gym_sbr2_amd.ShardedSbrOS (the class the sharding tests cover); the one collective of
+                       the path, an RCCL all-gather of the float32 episode returns, runs at every episode boundary (every 463
+                       calls).  A timed region shorter than an episode (the driver's `--steps 20 --warmup 5`) contains no
+                       boundary, so ONE all-gather is then issued after the K-th step, before the closing synchronise: the timed
+                       region of an N > 1 run always contains the collective, and `config.allgathers_in_timed_region` /
+                       `config.allgather_bytes_per_rank` say how many and how large.  The N = 1 workload is unchanged by this
+                       (no process group, no collective).  configs[3]'s shape at 65536 envs per GPU (per-GPU work fixed =>
+                       weak scaling; 8 GPUs = 524288 envs = 2 x configs[3]'s 262144; `--envs-per-gpu 32768` gives configs[3]
+                       itself).
     config1            4096 envs per GPU, deterministic influent (64 wavefronts: cannot fill 1024 SIMDs; a parity case)
     config5            65536 envs per GPU, fused on-device random-policy rollout (sbr_rollout), 463 calls per launch
     cycle              65536 envs per GPU of the per-cycle env SBR-v2: one launch = one whole cycle of 528
@@ -56,7 +61,7 @@ CALLS_PER_EPISODE = 463
 # the wave doses carbon 159 FMA x 2 + 104 MUL + 4 ADD + 4 RCP = 430; with dosing (the loop is unrolled by two: 426 x 2 + 229 +
 # 16 + 8 per two substeps) 552.  The loops only (no PIDs, reward, observations): a LOWER bound of the work per env-step.
 # tests/test_isa_cpu.py asserts both figures against the compiler's output.
-FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 552}
+FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 552, "filling": 590}      # filling: k_cycle's / k_reset's loop, (426 x 2 + 229 + 88 + 12) / 2
 SUBSTEPS = 10
 # vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
 # vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles
@@ -93,13 +98,59 @@ def cpu_baseline(n_envs=16384, calls=463, physical=True):
         for a in acts:
             b.step(a, want_obs=True)
         best = max(best, n_envs * calls / (time.perf_counter() - t0))
+    # "1 core and all cores" - the same port on ONE thread, a sample sized for about a second
+    n1 = 2048
+    b1 = O.OracleBatch(n1, nthreads=1)
+    infl1 = infl[:n1].copy()
+    best1 = 0.0
+    for _ in range(2):
+        b1.reset(infl1)
+        t0 = time.perf_counter()
+        for a in acts:
+            b1.step(a[:n1], want_obs=True)
+        best1 = max(best1, n1 * calls / (time.perf_counter() - t0))
     return {"value": best, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d step() calls of the same workload, oracle/sbr_oracle.c with %d OpenMP threads, best of 3"
                       % (n_envs, calls, cores),
+            "single_thread": {"value": best1, "unit": "env-steps/s", "cores": 1,
+                              "sample": "%d envs x %d step() calls of the same workload on one thread, best of 2" % (n1, calls)},
             "reference": REFERENCE_CPU}
 
 
+def pmc_record(lib_hash, profiles_dir=None):
+    """The committed PMC summary (scripts/pmc_summarise.py) that was measured on THE library being timed: the newest
+    profiles/r*_pmc_traffic.json whose `library_source_hash` equals `lib_hash` (the content hash of sources + flags that
+    gym_sbr2_amd.build writes next to the library it builds).  Returns (record, None) or (None, why not): a profile of another
+    kernel must not be pasted into this run's line."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_pmc_traffic.json")), reverse=True)
+    if not lib_hash:
+        return None, "the loaded library carries no source hash (an A/B variant?): no committed PMC profile can be matched to it"
+    seen = []
+    for path in paths:
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("library_source_hash") == lib_hash:
+            rec["_file"] = os.path.relpath(path, ROOT)
+            return rec, None
+        seen.append("%s: %s" % (os.path.basename(path), str(rec.get("library_source_hash"))[:12]))
+    return None, ("no committed PMC profile was measured on this library (source hash %s; found %s): re-run scripts/profile_round.sh "
+                  "and scripts/pmc_summarise.py" % (lib_hash[:12], "; ".join(seen) or "none"))
+
+
+def loaded_library_hash():
+    from gym_sbr2_amd import _capi
+    try:
+        with open(_capi.library_path() + ".srchash") as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 INTERVALS_PER_CYCLE = 528      # 24 + 48 + 223 + 186 + 11 + 36 control intervals (tests/golden/sbrv2_cycles.npz)
+FILL_INTERVALS = 24            # the first phase integrates the filling right-hand side
 
 
 def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
@@ -142,6 +193,23 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
         dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
     per_launch_s = e0.elapsed_time(e1) * 1e-3 / steps
     achieved = n_local * INTERVALS_PER_CYCLE * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
+    # float64 work of one cycle, RK4 substep loops only (ISA counts, tests/test_isa_cpu.py): 24 filling intervals + 504 closed ones
+    flop_per_cycle = SUBSTEPS * (FILL_INTERVALS * FP64_FLOP_PER_SUBSTEP["filling"]
+                                 + (INTERVALS_PER_CYCLE - FILL_INTERVALS) * FP64_FLOP_PER_SUBSTEP["plain"])
+    tflops = n_local * flop_per_cycle / per_launch_s / 1e12
+    fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+            "flop_per_env_step": flop_per_cycle / INTERVALS_PER_CYCLE,
+            "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work"}
+    rec, why = pmc_record(loaded_library_hash())
+    traffic = None
+    if rec and "cycle" in rec and n_local == rec.get("envs_per_launch", 65536):
+        waves = (n_local + 63) // 64
+        cyc = rec["cycle"]
+        traffic, why = cyc.get("hbm_bytes_per_launch"), "bytes per reset + cycle, a committed constant (%s, measured on this library)" % rec["_file"]
+        if cyc.get("valu_insts_per_wave"):
+            fp64["valu_insts_per_wave"] = cyc["valu_insts_per_wave"]
+            fp64["issue_slot_frac"] = (cyc["valu_insts_per_wave"] * 4.0 * (waves / SIMDS if waves > SIMDS else 1.0)
+                                       / (per_launch_s * MAX_CLOCK_GHZ * 1e9))
     out = {"metric": "env-steps/sec (batched)", "value": n_global * steps * INTERVALS_PER_CYCLE / elapsed, "unit": "env-steps/s",
            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -151,9 +219,10 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
                       "clock_priming_s": PRIME_SECONDS,
                       "kernel": "k_cycle<float,float> (+ k_cycle_reset)"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                        "traffic": None, "avg_launch_us": per_launch_s * 1e6,
-                        "note": "513 algorithmic bytes per control interval by the per-step convention; the fused kernel actually "
-                                "moves one load and one store of the plant per cycle - it is fp64-VALU-bound"}}
+                        "traffic": traffic, "traffic_unit": why, "avg_launch_us": per_launch_s * 1e6,
+                        "fp64_valu": fp64, "headline": "fp64_valu",
+                        "note": "FUSED kernel: `achieved`/`frac` are the 513-byte per-control-interval CONVENTION, not traffic - the kernel "
+                                "moves one load and one store of the plant per cycle; it is bound by float64 VALU issue: read fp64_valu"}}
     env.close()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -231,16 +300,17 @@ def main():
         state["episode"] += 1
         state["in_episode"] = 0
 
-    ret64 = torch.empty(n_local, dtype=torch.float64, device=dev)
+    gbufs = sh.gather_buffers(torch.float32)          # float64 row, float32 send, float32 [n_global] recv: allocated once, here
     status_snap = torch.empty(n_local, dtype=torch.float64, device=dev)
+    dist_up = world > 1 or force_dist
+    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0, "allgathers": 0}
 
     def end_of_episode():
-        # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync):
+        # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync, no allocation):
         # the per-env returns, collated over ranks by the one collective of the path (configs[3])
-        state["returns"] = sh.gather_episode_returns_async(out64=ret64)      # all_gather_into_tensor when a group is up
+        state["returns"] = sh.gather_episode_returns_into(gbufs)      # all_gather_into_tensor when a group is up
+        acct["allgathers"] += 1 if dist_up else 0
         env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
-
-    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0}
 
     def run(k_steps, record):
         done = 0
@@ -305,10 +375,12 @@ def main():
     run(min(args.warmup, 1), record=True)
     torch.cuda.synchronize(dev)
     seg_events.clear()
-    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0)
+    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0, allgathers=0)
     episodes_before = state["episode"]
     t0 = time.perf_counter()
     run(args.steps, record=True)
+    if dist_up and acct["allgathers"] == 0:     # no episode boundary fell into the K steps: the collective of the path still
+        end_of_episode()                        # runs once inside the timed region of an N > 1 run (returns so far)
     t_issued = time.perf_counter()              # (diagnostic) the host has issued every launch of the region
     torch.cuda.synchronize(dev)                 # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
     elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
@@ -328,22 +400,26 @@ def main():
     achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
     # HBM bytes per launch and VALU instructions per wave from the PMC counters: collected offline with rocprofv3 --pmc
     # (scripts/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE / SQ passes, gfx950 fetch correction calibrated in the same
-    # run) and committed under profiles/; valid for the default workload only
-    traffic, traffic_note, valu_per_wave = None, None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    rec = json.load(open(pmc)) if os.path.exists(pmc) else None
-    if rec and not fused and n_local == 65536 and args.workload == "config2":
+    # run) and committed under profiles/.  They are a COMMITTED CONSTANT, not a measurement of this run: attached only when the
+    # profile was taken on the very library that is being timed (content hash of sources + flags), for the profiled batch size
+    traffic, valu_per_wave = None, None
+    rec, traffic_note = pmc_record(loaded_library_hash())
+    if rec and n_local != rec.get("envs_per_launch", 65536):
+        rec, traffic_note = None, "the committed PMC profile is of %d envs per launch, this run has %d" % (rec.get("envs_per_launch", 65536), n_local)
+    if rec and not fused and args.workload == "config2":
         traffic = rec["hbm_bytes_per_launch"]
         valu_per_wave = rec.get("valu_insts_per_wave")
-        traffic_note = ("bytes per launch (profiles/r02_pmc_traffic.json: %.0f B per env-step vs %d algorithmic; the internal "
-                        "layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
-                        % (rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
-    elif rec and fused and n_local == 65536 and "rollout" in rec:
+        traffic_note = ("bytes per launch, a committed constant (%s, measured on this library: %.0f B per env-step vs %d algorithmic; "
+                        "the internal layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
+                        % (rec["_file"], rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
+    elif rec and fused and "rollout" in rec:
         rr = rec["rollout"]
         traffic = rr["hbm_bytes_per_launch"]
-        traffic_note = ("bytes per launch of %d calls (profiles/r02_pmc_traffic.json: %.1f B per env-step really moved; `achieved` "
-                        "uses the per-step convention of %d B)" % (rr["calls_per_launch"], rr["hbm_bytes_per_env_step"],
-                                                                  ALGO_BYTES_PER_ENV_STEP))
+        valu_per_wave = rr.get("valu_insts_per_wave")
+        traffic_note = ("bytes per launch of %d calls, a committed constant (%s, measured on this library: %.2f B per env-step really "
+                        "moved)" % (rr["calls_per_launch"], rec["_file"], rr["hbm_bytes_per_env_step"]))
+    elif rec:
+        traffic_note = "the committed PMC profile covers config2 and config5 only"
     # float64 work of the timed calls: RK4 loop only, by the code path the timed calls ran (the anoxic phases dose carbon)
     frac_dosing = acct["anoxic_calls"] / max(args.steps, 1)
     flop_per_step = SUBSTEPS * (frac_dosing * FP64_FLOP_PER_SUBSTEP["dosing"] + (1 - frac_dosing) * FP64_FLOP_PER_SUBSTEP["plain"])
@@ -354,11 +430,14 @@ def main():
             "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work; one wave per SIMD issues a "
                     "v_fma_f64 every 5.2 cycles and v_mul/v_add_f64 every 4.3 (scripts/probes/fp64_issue.hip), so ~0.8 of the "
                     "nominal peak is what a single resident wave can reach"}
-    if valu_per_wave and not fused:
-        # share of the VALU issue slots of the launch that carried an instruction: instructions per wave x 4 cycles (one wave64
-        # fp64 instruction at the nominal rate) x waves per SIMD / (launch time x max clock)
-        fp64["issue_slot_frac"] = valu_per_wave * 4.0 * (waves / SIMDS if waves > SIMDS else 1.0) / (per_launch_s * MAX_CLOCK_GHZ * 1e9)
-        fp64["valu_insts_per_wave"] = valu_per_wave
+    if valu_per_wave:
+        # share of the VALU issue slots of the launch that carried an instruction: instructions per wave (per launch: one call, or
+        # the 463 calls of a fused launch) x 4 cycles (one wave64 fp64 instruction at the nominal rate) x waves per SIMD /
+        # (launch time x max clock)
+        scale = calls_per_launch / rec["rollout"]["calls_per_launch"] if fused else 1.0
+        fp64["issue_slot_frac"] = (valu_per_wave * scale * 4.0 * (waves / SIMDS if waves > SIMDS else 1.0)
+                                   / (per_launch_s * MAX_CLOCK_GHZ * 1e9))
+        fp64["valu_insts_per_wave"] = valu_per_wave * scale
     workload = {"config1": "configs[1]: 4096 envs/GPU, fixed-step RK4 (10 substeps), deterministic influent, per-step API",
                 "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, fixed-step RK4 (10 substeps), per-step API",
                 "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload]
@@ -368,7 +447,8 @@ def main():
         rel = ("= configs[3]'s 262144" if n_global == 262144 else
                "= %.3g x configs[3]'s 262144 (weak scaling keeps the 1-GPU line's per-GPU batch)" % (n_global / 262144.0))
         workload += ("; configs[3] shape: sharded over %d GPUs by global env id (gym_sbr2_amd.ShardedSbrOS), one RCCL all-gather of the "
-                     "episode returns per episode inside the timed region; envs_total %d %s" % (world, n_global, rel))
+                     "episode returns per episode boundary, at least one inside the timed region (config.allgathers_in_timed_region); "
+                     "envs_total %d %s" % (world, n_global, rel))
     st_bits = status_snap.to(torch.int64)
     out = {
         "metric": "env-steps/sec (batched)",
@@ -381,6 +461,8 @@ def main():
         "config": {"workload": workload,
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
                    "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
+                   "allgathers_in_timed_region": acct["allgathers"],
+                   "allgather_bytes_per_rank": 4 * n_local if dist_up else 0,
                    "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",
                    "policy": args.policy,
                    "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
@@ -396,8 +478,13 @@ def main():
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
                                          "host_in_reset_issue": acct["reset_issue_ms"]},
                      "fp64_valu": fp64,
-                     "note": "the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
-                             "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu"},
+                     "headline": "fp64_valu" if fused else "hbm",
+                     "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
+                              "513-byte per-step CONVENTION, not traffic (`traffic` is what really moves); the kernel is bound by float64 "
+                              "VALU issue - read fp64_valu (issue_slot_frac = share of the VALU issue slots used, frac = FLOP share of the "
+                              "78.6 TFLOP/s vector peak)") if fused else
+                             ("the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
+                              "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu")},
         "env_status": {"near_pole_frac_last_episode": float(((st_bits & _capi.ST_NEAR_POLE) != 0).float().mean().item())
                        if state["episode"] > 2 else None,
                        "negative_frac_last_episode": float(((st_bits & _capi.ST_NEGATIVE) != 0).float().mean().item())

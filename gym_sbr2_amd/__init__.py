@@ -17,7 +17,8 @@ from .registration import make, register_with_gym, registered_ids  # noqa: F401,
 __version__ = "0.2.0"
 
 # The reference registers its ids when `gym_SBR` is imported (gym_SBR/__init__.py:3-12); so does this package, with
-# whichever of gymnasium / gym is installed (neither is in this image: then only gym_sbr2_amd.make() knows the ids).
+# whichever of gym / gymnasium is installed (neither is in this image: then only gym_sbr2_amd.make() knows the ids).
+# {library: [ids]}; a failed registration is a RuntimeWarning and is kept in registration.REGISTRATION_ERRORS, never dropped.
 REGISTERED_WITH = register_with_gym()
 
 

@@ -11,9 +11,9 @@ from . import build as _build
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
-NTRACE = 28          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
+NTRACE = 31          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
 (TR_T, TR_X0, TR_KLA, TR_EC, TR_REWARD, TR_DONE, TR_U_DO, TR_U_EC, TR_E_EC, TR_IE_EC, TR_DCV_EC, TR_R_EQI, TR_R_OCI, TR_R_AE,
- TR_R_EC) = (0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27)
+ TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST) = (0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30)
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
@@ -67,6 +67,7 @@ SYMBOLS = {
     "sbr_get_ctrl_row": (C.c_int, [_VP, _I32, _VP, _VP]),
     "sbr_get_influent": (C.c_int, [_VP, _VP, _VP]),
     "sbr_eval_rhs": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_eval_substeps": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_draw_normals": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_draw_scenarios": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_timer_start": (C.c_int, [_VP, _VP]),

@@ -517,6 +517,9 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
             const double ae2 = rp.ae * p.inv_ae_max, ec2 = rp.ec * p.inv_ec_max;
             rec[SBR_TR_R_EQI * b.n_trace] = rp.eqi2; rec[SBR_TR_R_OCI * b.n_trace] = ae2 + ec2;
             rec[SBR_TR_R_AE * b.n_trace] = ae2; rec[SBR_TR_R_EC * b.n_trace] = ec2;
+            // what rebuilding the sub-interval rows needs (sbr_eval_substeps): the intervals run and the first one's Kla / EC
+            rec[SBR_TR_N_IV * b.n_trace] = (double)c.n_new; rec[SBR_TR_KLA_FIRST * b.n_trace] = c.knew[0];
+            rec[SBR_TR_EC_FIRST * b.n_trace] = c.n_new > 1 ? c.ec_prev : c.ec_last;
         }
     } else {
         x6.get(xa6);
@@ -726,6 +729,27 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rhs(SbrPar p, int32_t kind, int64
     else sbr_rhs<2>(p, xv, kla[i], 0.0, ld, d);
 #pragma unroll
     for (int j = 0; j < SBR_NX; ++j) dx[i * SBR_NX + j] = d[j];
+}
+
+// RK4 nodes of one control interval and the right-hand side at each node (sbr_eval_substeps; trajectory export only).
+// Substep by substep with the dosing code path, whose flow terms are exact no-ops at ec == 0 (sbr_rk4): the nodes are those
+// sbr_step passes through, to rounding (V, Si, Xi and the charge balance are closed per substep here, per interval there).
+__global__ __launch_bounds__(SBR_BLOCK) void k_substeps(SbrPar p, int64_t n, const double* __restrict__ x0, const double* __restrict__ kla,
+                                                       const double* __restrict__ ec, const double* __restrict__ span,
+                                                       double* __restrict__ xs, double* __restrict__ dxs) {
+    const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double x[SBR_NX], nold[SBR_NX], d[SBR_NX];
+#pragma unroll
+    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[i * SBR_NX + j]; nold[j] = 0.0; }
+    const double h = span[i] * p.inv_substeps, k = kla[i], e = ec[i];
+    for (int s = 0; s <= p.substeps; ++s) {
+        sbr_rhs<0>(p, x, k, e, nold, d);
+        const int64_t o = (i * (p.substeps + 1) + s) * SBR_NX;
+#pragma unroll
+        for (int j = 0; j < SBR_NX; ++j) { xs[o + j] = x[j]; dxs[o + j] = d[j]; }
+        if (s < p.substeps) sbr_rk4<1>(p, x, h, 1, k, e, nold);
+    }
 }
 
 __global__ __launch_bounds__(SBR_BLOCK) void k_normals(SbrBuf b, uint64_t seed, double* __restrict__ out) {
@@ -1201,6 +1225,16 @@ int sbr_eval_rhs(sbr_env* e, int32_t kind, int64_t n, const double* x, const dou
     if (n > 0)
         hipLaunchKernelGGL(k_rhs, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, kind, n, x, kla, ec,
                            loading, dx);
+    HIP_TRY(e, hipGetLastError());
+    return SBR_OK;
+}
+
+int sbr_eval_substeps(sbr_env* e, int64_t n, const double* x0, const double* kla, const double* ec, const double* span,
+                      double* xs, double* dxs, void* stream) {
+    if (!e || !x0 || !kla || !ec || !span || !xs || !dxs || n < 0) return fail(e, SBR_ERR_INVALID, "sbr_eval_substeps: bad argument");
+    ON_DEVICE(e);
+    if (n > 0)
+        hipLaunchKernelGGL(k_substeps, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, n, x0, kla, ec, span, xs, dxs);
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

@@ -3,16 +3,16 @@ backed by the batched HIP environment at N = 1:  reset() -> ndarray[3];  step(a[
 import numpy as np
 import torch
 
+from .. import _gymcompat as _gym
 from ..cycle_env import SbrEnv2Vec
-from .sbr_os import _Box
 
 
-class SbrEnv2:
+class SbrEnv2(_gym.Env):
     metadata = {"render.modes": ["human"]}
 
     def __init__(self, device=0, seed=None):
-        self.action_space = _Box([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])                       # :64
-        self.observation_space = _Box([0.5, 0, 0], [1.33, 2.5, 2])                       # :66 (as declared upstream)
+        self.action_space = _gym.box([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])                   # :64
+        self.observation_space = _gym.box([0.5, 0, 0], [1.33, 2.5, 2])                   # :66 (as declared upstream)
         self._vec = SbrEnv2Vec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64)
         self._seed, self._episodes, self.reward = seed, 0, 0
 

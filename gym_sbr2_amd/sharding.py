@@ -48,6 +48,23 @@ def gather_returns(local, n_global, group=None):
     return torch.cat(parts)
 
 
+def gather_returns_into(row, send, recv, group=None):
+    """all_gather_into_tensor of equal shards through caller-owned buffers: `row` [n_local] (any float dtype) is cast into `send`
+    [n_local] and gathered into `recv` [world * n_local]; nothing is allocated.  Without a process group `recv` must be
+    [n_local] and receives the cast."""
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        if send.numel() * world != recv.numel() or row.numel() != send.numel():
+            raise ValueError("recv must hold world x n_local values (%d x %d != %d)" % (world, send.numel(), recv.numel()))
+        send.copy_(row)
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        if recv.numel() != row.numel():
+            raise ValueError("no process group: this rank holds a shard, not the whole batch")
+        recv.copy_(row)
+    return recv
+
+
 def local_device(env=None, n_devices=None):
     """The GPU this process should use when none is named: LOCAL_RANK (what torch.distributed.run exports for one process
     per GPU), modulo the number of visible devices; without a launcher, torch's current device.  Every rank defaulting to
@@ -88,13 +105,26 @@ class ShardedSbrOS:
     def rollout(self, n_steps, policy_seed=0):
         return self.env.rollout(n_steps, policy_seed)
 
-    def gather_episode_returns_async(self, out64=None, dtype=torch.float32):
-        """As gather_episode_returns, with a caller-owned float64 scratch row (no allocation on the launch stream)."""
-        return gather_returns(self.env.episode_returns(out=out64).to(dtype), self.n_global)
+    def gather_buffers(self, dtype=torch.float32):
+        """Caller-owned buffers for gather_episode_returns_into(): (float64 row [n_local], send [n_local] dtype, recv [n_global]
+        dtype) on this rank's device.  Only equal shards can be gathered without staging (all_gather_into_tensor)."""
+        if self.n_global % self.world != 0:
+            raise ValueError("gather_buffers needs equal shards (n_global % world == 0); use gather_episode_returns()")
+        dev, n = self.env.device, self.stop - self.start
+        return (torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=dtype, device=dev),
+                torch.empty(self.n_global, dtype=dtype, device=dev))
 
-    def gather_episode_returns(self, dtype=torch.float32):
-        """[n_global] episode returns on every rank: the single collective of the path."""
-        return gather_returns(self.env.episode_returns().to(dtype), self.n_global)
+    def gather_episode_returns_into(self, bufs, group=None):
+        """The single collective of the path with NOTHING allocated: the returns row is copied into bufs[0] (float64), cast
+        into bufs[1] and all-gathered into bufs[2] ([n_global], ordered by global env id), all on the current stream.  Returns
+        bufs[2].  Without a process group (world 1) the cast lands in bufs[2] directly."""
+        self.env.episode_returns(out=bufs[0])
+        return gather_returns_into(*bufs, group=group)
+
+    def gather_episode_returns(self, dtype=torch.float32, group=None):
+        """[n_global] episode returns on every rank: the single collective of the path (allocates its result; ragged shards
+        are padded).  gather_episode_returns_into() is the allocation-free form for equal shards."""
+        return gather_returns(self.env.episode_returns().to(dtype), self.n_global, group=group)
 
     def close(self):
         self.env.close()

@@ -270,6 +270,18 @@ class SbrOSVec:
                                           self._stream()), self._h)
         return dx
 
+    def eval_substeps(self, x0, kla, ec, span):
+        """RK4 nodes and node slopes of n independent control intervals (sbr_eval_substeps): x0 [n,14], kla/ec/span [n] ->
+        xs, dxs [n, substeps + 1, 14] float64.  For trajectory export (SbrOS.trajectory(dense=True))."""
+        x0 = torch.as_tensor(x0, dtype=torch.float64, device=self.device).contiguous()
+        n = x0.shape[0]
+        kla, ec, span = (self._dev(v, torch.float64, (n,)) for v in (kla, ec, span))
+        xs = torch.empty((n, int(self.cfg.substeps) + 1, _capi.NX), dtype=torch.float64, device=self.device)
+        dxs = torch.empty_like(xs)
+        _capi.check(self.lib.sbr_eval_substeps(self._h, n, _ptr(x0), _ptr(kla), _ptr(ec), _ptr(span), _ptr(xs), _ptr(dxs),
+                                               self._stream()), self._h)
+        return xs, dxs
+
     def draw_scenarios(self, seed):
         """The scenario every env draws at reset(seed, scenario=None) when the config has random_scenario = 1 ([N] int32)."""
         out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)

@@ -170,10 +170,13 @@ int sbr_reset_carry(sbr_env* env, uint64_t seed, const int32_t* scenario, const 
  * the caller; buf = NULL switches tracing off.  Record (SBR_TR_*): t, x[14] (end of the call), Kla, EC (of the call's last
  * interval), reward, done, the clipped set-points u_DO / u_EC in force (:862-870, :898-906), the NO3-PID's e_EC, ie_EC,
  * dcv_EC (:1918-1926, :2006-2014) and the four diagnostics sbr_reward appends (module_reward_EQIOCI.py:109-112):
- * EQI2, OCI2 = AE_OCI2 + EC_OCI2, AE_OCI2, EC_OCI2. */
-#define SBR_NTRACE 28
+ * EQI2, OCI2 = AE_OCI2 + EC_OCI2, AE_OCI2, EC_OCI2; then what a consumer needs to rebuild the reference's sub-interval rows
+ * (sbr_eval_substeps): the number of control intervals the call ran (1, or 2 on a phase-boundary call) and the Kla / EC of
+ * the FIRST of them (equal to SBR_TR_KLA / SBR_TR_EC when the call ran one). */
+#define SBR_NTRACE 31
 enum { SBR_TR_T = 0, SBR_TR_X0 = 1, SBR_TR_KLA = 15, SBR_TR_EC, SBR_TR_REWARD, SBR_TR_DONE, SBR_TR_U_DO, SBR_TR_U_EC,
-       SBR_TR_E_EC, SBR_TR_IE_EC, SBR_TR_DCV_EC, SBR_TR_R_EQI, SBR_TR_R_OCI, SBR_TR_R_AE, SBR_TR_R_EC };
+       SBR_TR_E_EC, SBR_TR_IE_EC, SBR_TR_DCV_EC, SBR_TR_R_EQI, SBR_TR_R_OCI, SBR_TR_R_AE, SBR_TR_R_EC,
+       SBR_TR_N_IV, SBR_TR_KLA_FIRST, SBR_TR_EC_FIRST };
 int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity);
 
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
@@ -230,6 +233,16 @@ int sbr_get_influent(sbr_env* env, double* out, void* stream);
  * kind: 0 reaction, 1 filling (needs loading), 2 idle. */
 int sbr_eval_rhs(sbr_env* env, int32_t kind, int64_t n, const double* x, const double* kla, const double* ec,
                  const double* loading, double* dx, void* stream);
+
+/* Dense output of ONE control interval, for trajectory export: the reference returns odeint's solution on the 9- or
+ * 10-point grid linspace(t, t + t_delta, int(t_delta/dt)) of every interval and appends those rows to t_t / x_t / So_t ...
+ * (gym_SBR_oneshot.py:1339, :1369, :1959-1961); a fixed-step integrator has its own nodes instead.  For n independent
+ * intervals given by start state x0 [n][14], the held Kla [n] and EC [n] and the interval length span [n] (days), this
+ * writes the cfg.substeps + 1 RK4 nodes xs [n][substeps + 1][14] (node 0 = x0, last node = the state sbr_step ends the
+ * interval in, to rounding) and the right-hand side at every node dxs [n][substeps + 1][14]: values and slopes for
+ * cubic-Hermite interpolation onto any grid.  DEVICE pointers.  Not on the stepping path. */
+int sbr_eval_substeps(sbr_env* env, int64_t n, const double* x0, const double* kla, const double* ec, const double* span,
+                      double* xs, double* dxs, void* stream);
 
 /* device-side normal draws used by sbr_reset when rnd == NULL, exposed for tests: out [N][48]. */
 int sbr_draw_normals(sbr_env* env, uint64_t seed, double* out, void* stream);

@@ -75,6 +75,13 @@ if len(cal_f) < 4 or len(cal_w) < 4:
 f_factor = mean(cal_f) * 1024 / CAL_BYTES          # ~0.50 on gfx950
 w_factor = mean(cal_w) * 1024 / CAL_BYTES          # ~1.00
 n_envs = 65536
+sys.path.insert(0, ROOT)
+from gym_sbr2_amd import build as _build  # noqa: E402
+hash_file = os.path.join(src, "library_source_hash.txt")
+lib_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else None
+if lib_hash != _build.source_hash():
+    print("WARNING: the profiled library (%s) is not what the source tree builds now (%s): bench.py will not attach this profile"
+          % (str(lib_hash)[:12], _build.source_hash()[:12]))
 fetch_raw = mean(fetch[step_k]) * 1024
 fetch_b = fetch_raw / f_factor
 write_b = mean(write[pick(write, "k_step<")]) * 1024 / w_factor
@@ -85,6 +92,7 @@ out = {
     "unit_note": "counter values are KiB.  Both counters are calibrated in their own pass on eight %d-byte device-to-device "
                  "copies (__amd_rocclr_copyBuffer): WRITE_SIZE/bytes = %.4f, FETCH_SIZE/bytes = %.4f (gfx950 tallies 128-byte "
                  "fetches at 64 bytes, MI355X_MICROARCH.md HBM section)" % (CAL_BYTES, w_factor, f_factor),
+    "library_source_hash": lib_hash,
     "envs_per_launch": n_envs, "kernel": short(step_k), "dispatches": len(fetch[step_k]),
     "FETCH_SIZE_raw_bytes": fetch_raw, "fetch_calibration_factor": f_factor, "write_calibration_factor": w_factor,
     "fetch_corrected_bytes": fetch_b, "WRITE_SIZE_bytes": write_b,
@@ -106,6 +114,15 @@ try:                                     # the fused rollout: one launch = a who
     print("k_rollout: %.2f MB per launch = %.2f B per env-step" % ((rf + rw) / 1e6, out["rollout"]["hbm_bytes_per_env_step"]))
 except SystemExit:
     print("no k_rollout dispatches in the PMC passes")
+try:                                     # the per-cycle kernel: one launch = 528 control intervals (+ its reset)
+    ck, crk = pick(fetch, "k_cycle<"), pick(fetch, "k_cycle_reset<")
+    cf = (mean(fetch[ck]) + mean(fetch[crk])) * 1024 / f_factor
+    cw = (mean(write[pick(write, "k_cycle<")]) + mean(write[pick(write, "k_cycle_reset<")])) * 1024 / w_factor
+    out["cycle"] = {"kernel": short(ck), "dispatches": len(fetch[ck]), "intervals_per_launch": 528,
+                    "hbm_bytes_per_launch": cf + cw, "hbm_bytes_per_env_step": (cf + cw) / n_envs / 528}
+    print("k_cycle + reset: %.2f MB per cycle = %.3f B per control interval" % ((cf + cw) / 1e6, out["cycle"]["hbm_bytes_per_env_step"]))
+except SystemExit:
+    print("no k_cycle dispatches in the PMC passes")
 try:                                     # dynamic VALU instructions per wave of k_step (SQ pass), for bench.py's issue_slot_frac
     sq0 = counters("pmc_sq")
     sk = pick(sq0["SQ_INSTS_VALU"], "k_step<")
@@ -116,6 +133,19 @@ try:                                     # dynamic VALU instructions per wave of
                          mean(sq0["SQ_WAIT_INST_ANY"][sk]) / mean(sq0["SQ_WAVE_CYCLES"][sk]),
                          mean(sq0["SQ_WAIT_ANY"][sk]) / mean(sq0["SQ_WAVE_CYCLES"][sk])))
     print("k_step: %.0f VALU instructions per wave" % out["valu_insts_per_wave"])
+    for key, needle, extra in (("rollout", "k_rollout<", None), ("cycle", "k_cycle<", "k_cycle_reset<")):
+        if key not in out:
+            continue
+        kk = pick(sq0["SQ_INSTS_VALU"], needle)
+        per_wave = max(sq0["SQ_INSTS_VALU"][kk]) / mean(sq0["SQ_WAVES"][kk])       # the full-length launches
+        if extra:
+            ek = pick(sq0["SQ_INSTS_VALU"], extra)
+            per_wave += mean(sq0["SQ_INSTS_VALU"][ek]) / mean(sq0["SQ_WAVES"][ek])
+        out[key]["valu_insts_per_wave"] = per_wave
+        i_full = max(range(len(sq0["SQ_INSTS_VALU"][kk])), key=lambda i: sq0["SQ_INSTS_VALU"][kk][i])
+        out[key]["sq_active_inst_any_over_wave_cycles"] = sq0["SQ_ACTIVE_INST_ANY"][kk][i_full] / sq0["SQ_WAVE_CYCLES"][kk][i_full]
+        out[key]["sq_wait_any_over_wave_cycles"] = sq0["SQ_WAIT_ANY"][kk][i_full] / sq0["SQ_WAVE_CYCLES"][kk][i_full]
+        print("%s: %.0f VALU instructions per wave and launch" % (needle, per_wave))
 except (SystemExit, KeyError, ZeroDivisionError):
     print("no SQ pass: valu_insts_per_wave not recorded")
 json.dump(out, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)

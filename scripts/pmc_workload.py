@@ -17,6 +17,7 @@ for _ in range(8):
     dst.copy_(src)
 torch.cuda.synchronize()
 print("calibration: 8 device-to-device copies of %d bytes" % CAL_BYTES, file=sys.stderr)
-for workload in ("config2", "config5"):          # per-step kernel, then the fused rollout (one launch = 463 calls)
-    sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "463", "--warmup", "20", "--workload", workload]
+# per-step kernel, the fused rollout (one launch = 463 calls), the per-cycle kernel (one launch = 528 control intervals)
+for workload, steps in (("config2", "463"), ("config5", "463"), ("cycle", "4")):
+    sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "20", "--workload", workload]
     runpy.run_path(sys.argv[0], run_name="__main__")

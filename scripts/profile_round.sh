@@ -8,6 +8,9 @@ set -e -o pipefail
 tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p $out
+# which library the profile is of: the content hash gym_sbr2_amd.build keeps next to it (bench.py attaches the PMC figures of
+# a committed profile only to a library with the same hash)
+python3 -c "from gym_sbr2_amd import build as b; b.build_library(); print(open(b.HASH).read().strip())" > $out/library_source_hash.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for w in config2 config1 config5 cycle; do
   timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err

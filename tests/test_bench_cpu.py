@@ -1,0 +1,48 @@
+"""Host logic of bench.py that needs no GPU: which committed PMC profile, if any, may be quoted in a run's JSON line."""
+import json
+import os
+import warnings
+
+from conftest import ROOT
+
+import bench
+from gym_sbr2_amd import build as B
+
+
+def _write(d, name, h, **kw):
+    rec = dict(library_source_hash=h, hbm_bytes_per_launch=38.8e6, hbm_bytes_per_env_step=592.5, envs_per_launch=65536, **kw)
+    with open(os.path.join(d, name), "w") as f:
+        json.dump(rec, f)
+
+
+def test_pmc_profile_is_quoted_only_for_the_library_it_was_measured_on(tmp_path):
+    d = str(tmp_path)
+    h = B.source_hash()
+    _write(d, "r07_pmc_traffic.json", h)
+    rec, why = bench.pmc_record(h, d)
+    assert why is None and rec["hbm_bytes_per_launch"] == 38.8e6 and rec["_file"].endswith("r07_pmc_traffic.json")
+    # one flipped character of the recorded hash (the kernel changed, the profile was not refreshed): the figure disappears
+    flipped = h[:-1] + ("0" if h[-1] != "0" else "1")
+    _write(d, "r07_pmc_traffic.json", flipped)
+    rec, why = bench.pmc_record(h, d)
+    assert rec is None and h[:12] in why and "r07_pmc_traffic.json" in why
+    # a library without a hash file (an A/B variant loaded through SBR_AMD_LIB) is never matched
+    _write(d, "r07_pmc_traffic.json", h)
+    assert bench.pmc_record(None, d)[0] is None
+    # round 2's profile carries no hash at all: never matched either; the newest matching round wins
+    _write(d, "r02_pmc_traffic.json", None)
+    _write(d, "r05_pmc_traffic.json", h, marker=5)
+    _write(d, "r06_pmc_traffic.json", flipped, marker=6)
+    _write(d, "r07_pmc_traffic.json", flipped)
+    assert bench.pmc_record(h, d)[0]["marker"] == 5
+    assert bench.pmc_record(h, str(tmp_path / "nowhere"))[0] is None
+
+
+def test_committed_profile_matches_the_sources_or_says_so():
+    """Not an error (a kernel edit legitimately outdates the profile, and bench.py then reports traffic = null with the reason):
+    a warning, so that the round's last profile refresh is not forgotten."""
+    rec, why = bench.pmc_record(B.source_hash())
+    if rec is None:
+        warnings.warn("profiles/ holds no PMC profile of the current kernel sources: " + why)
+    else:
+        assert rec["hbm_bytes_per_launch"] > 0 and os.path.exists(os.path.join(ROOT, rec["_file"]))

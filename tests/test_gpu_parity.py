@@ -168,6 +168,9 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
             assert abs(ctrl[_capi.C_QW][i] / float(e["term_Qw"]) - 1) < 1e-5
         else:                              # the reference's own default-tolerance LSODA noise exceeds the gate here (Ss only)
             print("[info] %s: device vs reference at default odeint tolerance: %.3f of the gate" % (name, worst_gold[i]))
+            # bounded all the same: no further than the reference's own tight-tolerance run is from it (2.58 / 1.35), + 5 %
+            own = gate(T[i]["step_x_end"][:ncall - 1], e["step_x_end"][:ncall - 1]).max()
+            assert worst_gold[i] < 3.0 and worst_gold[i] <= 1.05 * own + 0.05, (name, worst_gold[i], own)
         # the closed-loop bar on ALL six episodes: the reference itself at tight integrator tolerance
         t = T[i]
         assert worst_tight[i] <= 1.0, (name, worst_tight[i])                       # measured worst 0.51 (So, random_b)
@@ -664,6 +667,53 @@ def test_bench_workload_parity_at_65536_with_the_physical_policy(G, tables):
     env.close()
 
 
+def test_configs3_per_gpu_shape_against_oracle_and_the_unsharded_batch(G, tables):
+    """BASELINE.json configs[3] at ITS OWN per-GPU shape: rank 3 of 8 of a 262144-env batch = 32768 envs with global ids
+    98304..131071, which run in the 64-thread-workgroup build of k_step (SBR_SMALL_BATCH).  66 calls under the physical policy,
+    across the anoxic -> aerobic boundary (a double step), a 512-env oracle sample free-running; and the same global ids
+    stepped inside ONE 262144-env handle (256-thread workgroups, two waves per SIMD) give the same returns and states, bit for
+    bit: influent noise, scenario and arithmetic are keyed by the global env id, not by the shard."""
+    from gym_sbr2_amd import ShardedSbrOS
+    means, stds = tables
+    n_global, world, rank, calls = 262144, 8, 3, 66
+    sh = ShardedSbrOS(n_global, rank=rank, world=world, device=0)
+    n, first = sh.stop - sh.start, sh.start
+    assert (n, first) == (32768, 98304) and sh.env.first_env_id == first
+    scen_of = lambda gid: 4 + gid % 4                                  # noqa: E731 - the bench's physical workload
+    obs = _np(sh.reset(seed=1000, scenario_of=scen_of)).copy()
+    pick = np.r_[0:192, n // 2:n // 2 + 128, n - 192:n]                # first, middle, last wavefronts of the shard
+    ora = O.OracleBatch(len(pick))
+    z = np.stack([O.OracleBatch(1, first_env_id=int(first + i)).normals(1000)[0] for i in pick])
+    oobs = ora.reset(ora.mix(means, stds, scen_of(first + pick).astype(np.int32), z))
+    assert np.abs(obs[pick] - oobs).max() < 1e-5
+    gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+    pool = torch.rand(8, n_global, 2, device="cuda", generator=gen) * torch.tensor([2.5, 15.0], device="cuda")
+    big = G.SbrOSVec(n_global)
+    gid = torch.arange(n_global, device="cuda")
+    big.reset(seed=1000, scenario=scen_of(gid).to(torch.int32))
+    double_steps = 0
+    for c in range(calls):
+        a = pool[c & 7]
+        a_sh = a[first:first + n].contiguous()
+        o, s_, r, d = sh.step(a_sh)
+        big.step(a)
+        t_before = ora.envs["t"][0]
+        oo, os_, orr, od = ora.step(_np(a_sh)[pick].astype(np.float64))
+        double_steps += int(ora.envs["t"][0] - t_before > 1.5 * 0.002 / 24 * 10)
+        assert np.array_equal(_np(d)[pick], od)
+        if c % 6 == 0 or c >= calls - 2:
+            x, _ = sh.env.get_state()
+            g = gate(_np(x).T[pick], ora.envs["x"]).max()
+            assert g < 1e-6, (c, g)                                    # free-running, every sampled env
+            assert np.allclose(_np(r)[pick], orr, rtol=2e-7, atol=1e-10) and np.abs(_np(o)[pick] - oo).max() < 1e-5
+    assert double_steps == 1                                           # call 46 ran the last anoxic and the first aerobic interval
+    x_sh, c_sh = sh.env.get_state()
+    x_big, c_big = big.get_state()
+    assert torch.equal(x_sh, x_big[:, first:first + n]) and torch.equal(c_sh, c_big[:, first:first + n])
+    assert torch.equal(sh.env.episode_returns(), big.episode_returns()[first:first + n])
+    sh.close(); big.close()
+
+
 def test_indexing_at_134_million_envs(G):
     """Maximum sizes: 2**27 envs in ONE handle (51 GB of plant/controller/influent rows; element indices into the ctrl
     block pass 2**31 from row 16 on, obs offsets pass 2**31 at env 119 M).  Envs are independent and keyed by their global
@@ -939,6 +989,46 @@ def test_reference_shaped_single_env(G):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["const_2_5", "random_a"])
+def test_dense_trajectory_on_the_reference_output_grid(G, name):
+    """trajectory(dense=True): the rows the reference appends per control interval (gym_SBR_oneshot.py:1339, :1359-1369,
+    :876-892) - t_range[1:], x_out[1:], x_out[:-1, k], len - 1 copies of the set-points - rebuilt from the RK4 nodes by cubic
+    Hermite interpolation.  Against the reference's OWN lists and LSODA rows of the golden episode: the time grid bit for bit,
+    the states inside the parity gate (closed loop: an episode the default-tolerance run can be followed on)."""
+    e = golden("sbros_" + name)
+    env = G.make("SBROS-v1")
+    env.reset(rnd=e["rnd"])
+    for k in range(463):
+        env.step(e["actions"][k])
+    per_call = env.trajectory(as_dict=True)
+    d = env.trajectory(as_dict=True, dense=True)
+    rows = e["iv_n_rows"]                                   # 9 or 10 output rows per interval, 466 intervals
+    n_dense = int((rows - 1).sum())
+    assert n_dense == 3994 and len(d["t_t"]) == n_dense and d["x_t"].shape == (n_dense, 14)
+    # the reference's t_t is [0] + 251 fill rows + these + the terminal phases' rows: the same doubles
+    assert np.array_equal(np.array(d["t_t"]), e["traj_t_t"][252:252 + n_dense])
+    ref_rows = np.vstack([e["iv_x_rows"][i, 1:rows[i]] for i in range(466)])
+    assert np.array_equal(np.array(d["t_t"]), np.concatenate([e["iv_t_rows"][i, 1:rows[i]] for i in range(466)]))
+    g = gate(d["x_t"], ref_rows)
+    assert g.max() <= 1.0, g.max()
+    # the concentration lists take x_out[:-1]: start row in, end row out; the reference's own lists (after the 251 fill rows)
+    for key, j, scale in (("So_t", 8, 8.0), ("Sno_t", 9, 20.0), ("Snh_t", 10, 20.0)):
+        ref = e["traj_" + key][251:251 + n_dense]
+        assert len(d[key]) == n_dense and (np.abs(np.array(d[key]) - ref) <= 1e-5 * np.abs(ref) + 1e-5 * scale).all(), key
+    assert np.allclose(np.array(d["Ss_t"]), np.concatenate([[env._x_postfill[2]], d["x_t"][:-1, 2]]), rtol=1e-12, atol=0)
+    # set-points: len - 1 copies per interval of what was in force in THAT interval (both intervals of a boundary call)
+    assert np.array_equal(np.array(d["u_DO_t"]), np.repeat(e["iv_u_DO"], rows - 1))
+    assert np.array_equal(np.array(d["u_EC_t"]), np.repeat(e["iv_u_EC"], rows - 1))
+    # the last row of a call's last interval is the state step() returned (the per-call record), to rounding
+    ends = np.cumsum(rows - 1)[np.searchsorted(e["iv_call"], np.arange(463), side="right") - 1] - 1
+    rel = np.abs(d["x_t"][ends[:462]] - per_call["x_t"][:462]) / (np.abs(per_call["x_t"][:462]) + 1e-9)
+    assert rel.max() < 1e-12, rel.max()
+    # the lists that are per call upstream too are untouched by dense=True
+    assert np.array_equal(d["reward_t"], per_call["reward_t"]) and len(d["EC"]) == 463
+    env.close()
+
+
+@pytest.mark.gpu
 def test_random_scenario_is_drawn_on_the_device(G, tables):
     """cfg.random_scenario = 1: reset(scenario=None) gives every env one of the 8 influent scenarios, uniformly, as
     SbrEnv4.reset does with np.random.choice(8, 1) (gym_SBR_env4.py:107) - Philox stream 2 keyed by the seed of the reset
@@ -1171,3 +1261,14 @@ def test_bench_line_contract(force_dist):
     assert r["launches_timed"] == 20 and abs(t["step_kernels_device"] - 20 * r["avg_launch_us"] * 1e-3) < 1e-9
     assert t["step_kernels_device"] <= t["wall"] and t["host_issue"] <= t["wall"]
     assert 8.0 < r["avg_launch_us"] < 40.0 and d["value"] > 1e9            # sanity: the order of magnitude of this kernel
+    # the one collective of the path (configs[3]): a 20-step region holds no episode boundary, so an N > 1 run issues it once
+    # after the K-th step, inside the timed region; an N = 1 run without a process group has none
+    c = d["config"]
+    assert c["resets_in_timed_region"] == 0
+    if force_dist:
+        assert c["allgathers_in_timed_region"] >= 1 and c["allgather_bytes_per_rank"] == 4 * 65536
+    else:
+        assert c["allgathers_in_timed_region"] == 0 and c["allgather_bytes_per_rank"] == 0
+    # PMC traffic is a committed constant: present only if profiles/ holds a profile of THIS library (same source hash)
+    assert (r["traffic"] is None) or ("committed constant" in r["traffic_unit"] and r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"])
+    assert r["traffic"] is not None or r["traffic_unit"]

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gym_sbr2_amd.sharding import gather_returns, local_device, shard_range
+from gym_sbr2_amd.sharding import gather_returns, gather_returns_into, local_device, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -51,6 +51,14 @@ def _worker(rank, world, n_global, port, out_dir):
         start, stop = shard_range(n_global, rank, world)
         local = torch.from_numpy(_shard_returns(n_global, start, stop)).to(torch.float32)
         full = gather_returns(local, n_global)
+        if n_global % world == 0:          # the allocation-free form bench.py uses: float64 row -> float32 send -> preallocated recv
+            row = torch.from_numpy(_shard_returns(n_global, start, stop))
+            send, recv = torch.empty(stop - start, dtype=torch.float32), torch.full((n_global,), float("nan"), dtype=torch.float32)
+            addr = recv.data_ptr()
+            out = gather_returns_into(row, send, recv)
+            assert out is recv and recv.data_ptr() == addr and torch.equal(recv, full)
+            with pytest.raises(ValueError):
+                gather_returns_into(row, send, torch.empty(n_global + 1, dtype=torch.float32))
         dist.barrier()
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     finally:
@@ -73,6 +81,14 @@ def test_gather_without_process_group_is_identity():
     assert torch.equal(gather_returns(v, 5), v)
     with pytest.raises(ValueError):
         gather_returns(v, 6)
+
+
+def test_gather_into_without_process_group_is_a_cast():
+    row = torch.arange(5, dtype=torch.float64) / 3
+    send, recv = torch.empty(5, dtype=torch.float32), torch.empty(5, dtype=torch.float32)
+    assert gather_returns_into(row, send, recv) is recv and torch.equal(recv, row.to(torch.float32))
+    with pytest.raises(ValueError):
+        gather_returns_into(row, send, torch.empty(10, dtype=torch.float32))
 
 
 def test_local_device_follows_local_rank():
