@@ -67,7 +67,7 @@ SYMBOLS = {
     "sbr_get_ctrl_row": (C.c_int, [_VP, _I32, _VP, _VP]),
     "sbr_get_influent": (C.c_int, [_VP, _VP, _VP]),
     "sbr_eval_rhs": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "sbr_eval_substeps": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "sbr_eval_substeps": (C.c_int, [_VP, _I32, _I64, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_draw_normals": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_draw_scenarios": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_timer_start": (C.c_int, [_VP, _VP]),

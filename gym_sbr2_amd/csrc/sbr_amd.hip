@@ -731,24 +731,39 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_rhs(SbrPar p, int32_t kind, int64
     for (int j = 0; j < SBR_NX; ++j) dx[i * SBR_NX + j] = d[j];
 }
 
-// RK4 nodes of one control interval and the right-hand side at each node (sbr_eval_substeps; trajectory export only).
-// Substep by substep with the dosing code path, whose flow terms are exact no-ops at ec == 0 (sbr_rk4): the nodes are those
-// sbr_step passes through, to rounding (V, Si, Xi and the charge balance are closed per substep here, per interval there).
-__global__ __launch_bounds__(SBR_BLOCK) void k_substeps(SbrPar p, int64_t n, const double* __restrict__ x0, const double* __restrict__ kla,
-                                                       const double* __restrict__ ec, const double* __restrict__ span,
+// RK4 nodes of one integration span and the right-hand side at each node (sbr_eval_substeps; trajectory export only).
+// kind 0: a control interval (reaction_dxdt with Kla and EC held) - substep by substep with the dosing code path, whose flow
+// terms are exact no-ops at ec == 0 (sbr_rk4), so the nodes are those sbr_step passes through, to rounding (V, Si, Xi and the
+// charge balance are closed per substep here, per interval there); kind 1: the fill phase (filling_dxdt, loading vector);
+// kind 2: the idle phase (idle_dxdt); kind 3: settle + draw applied to x0 first (Sim_Settling_Drawing), then the idle phase -
+// node 0 is then the reactor after the draw.
+__global__ __launch_bounds__(SBR_BLOCK) void k_substeps(SbrPar p, int32_t kind, int64_t n, int32_t n_sub, const double* __restrict__ x0,
+                                                       const double* __restrict__ kla, const double* __restrict__ ec,
+                                                       const double* __restrict__ loading, const double* __restrict__ hstep,
                                                        double* __restrict__ xs, double* __restrict__ dxs) {
     const int64_t i = (int64_t)blockIdx.x * SBR_BLOCK + threadIdx.x;
     if (i >= n) return;
-    double x[SBR_NX], nold[SBR_NX], d[SBR_NX];
+    double x[SBR_NX], ld[SBR_NX], d[SBR_NX];
 #pragma unroll
-    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[i * SBR_NX + j]; nold[j] = 0.0; }
-    const double h = span[i] * p.inv_substeps, k = kla[i], e = ec[i];
-    for (int s = 0; s <= p.substeps; ++s) {
-        sbr_rhs<0>(p, x, k, e, nold, d);
-        const int64_t o = (i * (p.substeps + 1) + s) * SBR_NX;
+    for (int j = 0; j < SBR_NX; ++j) { x[j] = x0[i * SBR_NX + j]; ld[j] = (kind == 1) ? loading[i * SBR_NX + j] : 0.0; }
+    if (kind == 3) {
+        double sx[10], sx_eff;
+        const double xf = sbr_settle(p, x, p.t_settle * p.t_cycle, sx);
+        (void)sbr_draw(p, x, sx, xf, sx_eff);
+    }
+    const double h = hstep[i], k = kla[i], e = (kind == 0) ? ec[i] : 0.0;
+    for (int s = 0; s <= n_sub; ++s) {
+        if (kind == 0) sbr_rhs<0>(p, x, k, e, ld, d);
+        else if (kind == 1) sbr_rhs<1>(p, x, k, 0.0, ld, d);
+        else sbr_rhs<2>(p, x, k, 0.0, ld, d);
+        const int64_t o = (i * ((int64_t)n_sub + 1) + s) * SBR_NX;
 #pragma unroll
         for (int j = 0; j < SBR_NX; ++j) { xs[o + j] = x[j]; dxs[o + j] = d[j]; }
-        if (s < p.substeps) sbr_rk4<1>(p, x, h, 1, k, e, nold);
+        if (s < n_sub) {
+            if (kind == 0) sbr_rk4<1>(p, x, h, 1, k, e, ld);
+            else if (kind == 1) sbr_rk4<2>(p, x, h, 1, k, ld[0], ld);
+            else sbr_rk4<0>(p, x, h, 1, k, 0.0, ld);
+        }
     }
 }
 
@@ -1229,12 +1244,15 @@ int sbr_eval_rhs(sbr_env* e, int32_t kind, int64_t n, const double* x, const dou
     return SBR_OK;
 }
 
-int sbr_eval_substeps(sbr_env* e, int64_t n, const double* x0, const double* kla, const double* ec, const double* span,
-                      double* xs, double* dxs, void* stream) {
-    if (!e || !x0 || !kla || !ec || !span || !xs || !dxs || n < 0) return fail(e, SBR_ERR_INVALID, "sbr_eval_substeps: bad argument");
+int sbr_eval_substeps(sbr_env* e, int32_t kind, int64_t n, int32_t n_sub, const double* x0, const double* kla, const double* ec,
+                      const double* loading, const double* h, double* xs, double* dxs, void* stream) {
+    if (!e || !x0 || !kla || !h || !xs || !dxs || n < 0 || n_sub < 1 || n_sub > (1 << 20) || kind < 0 || kind > 3 ||
+        (kind == 0 && !ec) || (kind == 1 && !loading))
+        return fail(e, SBR_ERR_INVALID, "sbr_eval_substeps: bad argument");
     ON_DEVICE(e);
     if (n > 0)
-        hipLaunchKernelGGL(k_substeps, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, n, x0, kla, ec, span, xs, dxs);
+        hipLaunchKernelGGL(k_substeps, grid_for(n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, kind, n, n_sub, x0, kla, ec,
+                           loading, h, xs, dxs);
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

@@ -24,14 +24,22 @@ _Box = _gym._Box          # (kept for callers that imported the stand-in from he
 
 
 def _hermite(nodes, slopes, span, tau):
-    """Cubic Hermite interpolation of the S + 1 equidistant nodes [S+1, 14] with slopes [S+1, 14] over [0, span] at tau [m]."""
+    """Hermite interpolation of the S + 1 equidistant nodes [S+1, 14] with slopes [S+1, 14] over [0, span] at tau [m]: the
+    quintic through the values and slopes of the THREE nodes nearest to each tau (error O(h^6), well below the integrator's
+    own; the cubic between two nodes, O(h^4), would add up to half a parity gate to the rows between the nodes).  With u the
+    distance to the middle node in substeps and l_i the Lagrange polynomials of the nodes -1, 0, 1:
+    y = sum_i y_i (1 - 2 l_i'(u_i)(u - u_i)) l_i(u)^2 + h y'_i (u - u_i) l_i(u)^2."""
     s_n = nodes.shape[0] - 1
     h = span / s_n
-    k = np.minimum((tau / h).astype(int), s_n - 1)
-    th = ((tau - k * h) / h)[:, None]
-    h00, h10 = 2 * th ** 3 - 3 * th ** 2 + 1, th ** 3 - 2 * th ** 2 + th
-    h01, h11 = -2 * th ** 3 + 3 * th ** 2, th ** 3 - th ** 2
-    return h00 * nodes[k] + h10 * h * slopes[k] + h01 * nodes[k + 1] + h11 * h * slopes[k + 1]
+    if s_n < 2:                                  # two nodes only: the cubic
+        th = (tau / h)[:, None]
+        h00, h10, h01, h11 = 2 * th ** 3 - 3 * th ** 2 + 1, th ** 3 - 2 * th ** 2 + th, -2 * th ** 3 + 3 * th ** 2, th ** 3 - th ** 2
+        return h00 * nodes[0] + h10 * h * slopes[0] + h01 * nodes[1] + h11 * h * slopes[1]
+    m = np.clip(np.rint(tau / h).astype(int), 1, s_n - 1)
+    u = (tau / h - m)[:, None]
+    lm, l0, lp = u * (u - 1) / 2, 1 - u * u, u * (u + 1) / 2
+    out = (1 + 3 * (u + 1)) * lm ** 2 * nodes[m - 1] + l0 ** 2 * nodes[m] + (1 - 3 * (u - 1)) * lp ** 2 * nodes[m + 1]
+    return out + h * ((u + 1) * lm ** 2 * slopes[m - 1] + u * l0 ** 2 * slopes[m] + (u - 1) * lp ** 2 * slopes[m + 1])
 
 
 class SbrOS(_gym.Env):
@@ -47,7 +55,7 @@ class SbrOS(_gym.Env):
         self._seed = seed
         self._episodes = 0
         self._rewards, self._states, self._actions = [], [], []
-        self._x_postfill = None
+        self._x_postfill = self._x_prefill = self._influent = None
 
     def seed(self, seed=None):
         self._seed = seed
@@ -65,11 +73,14 @@ class SbrOS(_gym.Env):
         self._episodes += 1
         self._rewards, self._states, self._actions = [], [], []
         self._trace = self._vec.enable_trace(1, 464)
+        self._x_prefill = (self._vec.get_state()[0][:, 0].cpu().numpy() if carry_over
+                           else np.array(list(self._vec.cfg.x0), dtype=np.float64))      # where the fill phase starts
         obs = self._vec.reset(seed=seed, carry_over=carry_over,
                               scenario=None if scenario is None else [int(scenario)],
                               rnd=None if rnd is None else np.asarray(rnd, dtype=np.float64)[None],
                               influent=None if influent is None else np.asarray(influent, dtype=np.float64)[None])
         self._x_postfill = self._vec.get_state()[0][:, 0].cpu().numpy()       # where the first interval starts (dense trajectory)
+        self._influent = self._vec.influent()[:, 0].cpu().numpy()              # the loading vector, [0] = inflow during the fill
         return self._split(obs[0].cpu())
 
     def step(self, action):
@@ -95,16 +106,45 @@ class SbrOS(_gym.Env):
         return out
 
     def _dense_rows(self, rec):
-        """The reference's sub-interval rows of the running episode: for every control interval the solution on ITS output grid
+        """The reference's sub-interval rows of the running episode.  The reference appends odeint's solution on an output grid
+        of its own: the fill phase on linspace(0, T_fill, 252) (:296-313), every control interval on
         t_range = linspace(t, t + t_delta, int(((t + t_delta) - t)/dt)) (:1339, :1384: 9 or 10 points with the rounding of the
-        span), from which it appends t_range[1:] to t_t, x_out[1:] to x_t, x_out[:-1, k] to So_t / Ss_t / Sno_t / Snh_t and
-        len - 1 copies of the set-points to u_DO_t / u_EC_t (:1359-1369, :876-892).  LSODA interpolates its own steps onto that
-        grid; here the RK4 nodes of every interval and the right-hand side at them come from the device (sbr_eval_substeps,
-        replayed from the recorded start state, Kla and EC of the interval) and are interpolated by cubic Hermite polynomials
-        - fourth order like the integrator, exact at the nodes, so the last row of an interval is the state step() returned."""
+        span; t_range[1:] to t_t, x_out[1:] to x_t, x_out[:-1, k] to So_t / Ss_t / Sno_t / Snh_t, len - 1 copies of the set-points
+        to u_DO_t / u_EC_t, :1359-1369, :876-892), and on the done call constant rows over the settle and draw grids and the idle
+        phase on linspace(t_after_draw, t_cycle, n) (:1122-1155).  LSODA interpolates its own steps onto those grids; here the
+        RK4 nodes of every span and the right-hand side at them come from the device (sbr_eval_substeps, replayed from the
+        recorded start state, Kla and EC) and are interpolated by Hermite polynomials (quintic through three nodes, `_hermite`) -
+        exact at the nodes, so the last row of an interval is the state step() returned.  The grids are formed with the
+        reference's own NumPy calls: t_t equals the reference's list bit for bit."""
         from .. import _capi as K
-        cfg = self._vec.cfg
+        cfg, vec = self._vec.cfg, self._vec
         dt, t_delta, n = cfg.dt, cfg.t_delta, rec.shape[0]
+        out = {k: [] for k in ("t_t", "x_t", "So_t", "Ss_t", "Sno_t", "Snh_t", "u_DO_t", "u_EC_t")}
+        conc = (("So_t", 8), ("Ss_t", 2), ("Sno_t", 9), ("Snh_t", 10))
+
+        def np_(pair):
+            return tuple(v.cpu().numpy() for v in pair)
+
+        # ---- fill phase (reset): 252 rows, the first one the start state; Kla from the DO-PID at t = 0 (:1593-1617)
+        x_pre, infl = self._x_prefill, self._influent
+        rows_f = int((cfg.T_fill - 0) / dt)
+        e0 = 0.0 - x_pre[8]
+        kla_f = min(max(cfg.Kc_DO * e0 + (cfg.Kc_DO / cfg.tauI_DO) * 0.0, cfg.Kla_min), cfg.Kla_max)
+        xs, dx = np_(vec.eval_substeps(x_pre[None], [kla_f], [cfg.T_fill / rows_f], loading=infl[None], kind=1, n_sub=rows_f))
+        grid = np.linspace(0, cfg.T_fill, rows_f)
+        rows = _hermite(xs[0], dx[0], cfg.T_fill, grid)
+        rows[0], rows[-1] = xs[0, 0], xs[0, -1]
+        out["t_t"] += grid.tolist()
+        out["x_t"].append(rows)
+        for name, j in conc:
+            out[name] += rows[:-1, j].tolist()
+        out["u_DO_t"] += [0, kla_f] * (rows_f // 2)                    # Kla * int(len(x_out)/len(Kla)) with Kla = [0, k_fill], :320
+        out["u_EC_t"] += [0, 0.0] * (rows_f // 2)                      # EC likewise (:321)
+        if n == 0:
+            out["x_t"] = np.vstack(out["x_t"])
+            return out
+
+        # ---- control intervals
         n_iv = rec[:, K.TR_N_IV].astype(int)
         t_end = rec[:, K.TR_T]
         t0 = np.concatenate([[cfg.T_fill], t_end[:-1]])
@@ -120,13 +160,12 @@ class SbrOS(_gym.Env):
             return (a0, 0.0) if aerobic else (0.0, a1)
 
         live = np.nonzero(n_iv >= 1)[0]
-        xs1, dx1 = (v.cpu().numpy() for v in self._vec.eval_substeps(x0[live], first_kla[live], first_ec[live], span_of(t0[live])))
+        xs1, dx1 = np_(vec.eval_substeps(x0[live], first_kla[live], span_of(t0[live]) / cfg.substeps, ec=first_ec[live]))
         two = np.nonzero(n_iv[live] >= 2)[0]
         if len(two):
             t_mid = t0[live][two] + t_delta
-            xs2, dx2 = (v.cpu().numpy() for v in self._vec.eval_substeps(xs1[two, -1], rec[live][two, K.TR_KLA],
-                                                                          rec[live][two, K.TR_EC], span_of(t_mid)))
-        out = {k: [] for k in ("t_t", "x_t", "So_t", "Ss_t", "Sno_t", "Snh_t", "u_DO_t", "u_EC_t")}
+            xs2, dx2 = np_(vec.eval_substeps(xs1[two, -1], rec[live][two, K.TR_KLA], span_of(t_mid) / cfg.substeps,
+                                             ec=rec[live][two, K.TR_EC]))
 
         def emit(t_start, nodes, slopes, u_do, u_ec):
             span = span_of(t_start)
@@ -135,22 +174,46 @@ class SbrOS(_gym.Env):
             rows[0], rows[-1] = nodes[0], nodes[-1]
             out["t_t"] += grid[1:].tolist()
             out["x_t"].append(rows[1:])
-            for name, j in (("So_t", 8), ("Ss_t", 2), ("Sno_t", 9), ("Snh_t", 10)):
+            for name, j in conc:
                 out[name] += rows[:-1, j].tolist()
             out["u_DO_t"] += [u_do] * (len(grid) - 1)
             out["u_EC_t"] += [u_ec] * (len(grid) - 1)
 
         second = {int(live[j]): i for i, j in enumerate(two)}
+        x_last = None
         for i, k in enumerate(live):
             k = int(k)
             if k in second:
-                u = setpoints(t0[k], self._actions[k])
-                emit(t0[k], xs1[i], dx1[i], *u)
+                emit(t0[k], xs1[i], dx1[i], *setpoints(t0[k], self._actions[k]))
                 j = second[k]
                 emit(t0[k] + t_delta, xs2[j], dx2[j], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC])
+                x_last = xs2[j, -1]
             else:
                 emit(t0[k], xs1[i], dx1[i], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC])
-        out["x_t"] = np.vstack(out["x_t"]) if out["x_t"] else np.empty((0, 14))
+                x_last = xs1[i, -1]
+
+        # ---- the done call: settle and draw rows are constant (x before / after the draw, :2322-2323, :2411-2413), then idle
+        if rec[-1, K.TR_DONE] == 1.0 and cfg.terminal and x_last is not None:
+            t_last = rec[-1, K.TR_T]
+            g_set = np.linspace(t_last, t_last + cfg.t_settle * cfg.t_cycle, int((cfg.t_settle * cfg.t_cycle) / t_delta))
+            g_draw = np.linspace(g_set[-1], g_set[-1] + cfg.t_draw * cfg.t_cycle, int((cfg.t_draw * cfg.t_cycle) / t_delta))
+            t_idle0 = g_draw[-1]
+            g_idle = np.linspace(t_idle0, cfg.t_cycle, int((cfg.t_cycle - t_idle0) / dt))
+            n_idle = len(g_idle)
+            kla_idle = float(vec.ctrl_row(K.C_KLA_LAST)[0].item())       # Sim_idle's DO-PID output, left in Kla[-1] by the done call
+            span = cfg.t_cycle - t_idle0
+            xi, di = np_(vec.eval_substeps(x_last[None], [kla_idle], [span / n_idle], kind=3, n_sub=n_idle))
+            r_idle = _hermite(xi[0], di[0], span, np.clip(g_idle - t_idle0, 0.0, span))
+            r_idle[0], r_idle[-1] = xi[0, 0], xi[0, -1]
+            x_out1 = np.vstack([np.repeat(x_last[None], len(g_set), 0), np.repeat(xi[0, :1], len(g_draw) - 1, 0)])
+            t_all = np.concatenate([g_set, g_draw[1:], g_idle[1:]])
+            out["t_t"] += t_all[1:].tolist()
+            out["x_t"].append(np.vstack([x_out1, r_idle[1:]])[1:])
+            for name, j in conc:
+                out[name] += x_out1[:-1, j].tolist() + r_idle[:-1, j].tolist()
+            out["u_DO_t"] += [out["u_DO_t"][-1]] * (len(t_all) - 1)                 # :1153-1154
+            out["u_EC_t"] += [out["u_EC_t"][-1]] * (len(t_all) - 1)
+        out["x_t"] = np.vstack(out["x_t"])
         return out
 
     def trajectory(self, as_dict=False, dense=False):
@@ -167,9 +230,9 @@ class SbrOS(_gym.Env):
         (module_reward_EQIOCI.py:109-112) are per call in the reference too.  state_t, which the reference leaves empty
         (its append is commented out, :436), holds the state vector step() returned.
         as_dict=True returns the same arrays by name (plus Kla, the DO controller's output).
-        dense=True returns t_t, x_t, So_t, Ss_t, Sno_t, Snh_t, u_DO_t and u_EC_t on the reference's sub-interval grid instead
-        (8 or 9 rows per control interval, `_dense_rows`): the entries the reference's lists hold for the reaction intervals,
-        i.e. without the 252 rows of the fill phase in front and the rows of settle / draw / idle at the end."""
+        dense=True returns t_t, x_t, So_t, Ss_t, Sno_t, Snh_t, u_DO_t and u_EC_t on the reference's sub-interval grids instead
+        (`_dense_rows`): 252 rows of the fill phase, 8 or 9 rows per control interval, and after the done call the rows of
+        settle, draw and idle - the reference's lists entry for entry (4767 time points for a whole episode)."""
         from .. import _capi as K
         n = len(self._rewards)
         rec = self._trace[:n].cpu().numpy()[:, :, 0]

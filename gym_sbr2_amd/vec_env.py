@@ -270,16 +270,20 @@ class SbrOSVec:
                                           self._stream()), self._h)
         return dx
 
-    def eval_substeps(self, x0, kla, ec, span):
-        """RK4 nodes and node slopes of n independent control intervals (sbr_eval_substeps): x0 [n,14], kla/ec/span [n] ->
-        xs, dxs [n, substeps + 1, 14] float64.  For trajectory export (SbrOS.trajectory(dense=True))."""
+    def eval_substeps(self, x0, kla, h, ec=None, loading=None, kind=0, n_sub=None):
+        """RK4 nodes and node slopes of n independent integration spans (sbr_eval_substeps): x0 [n,14], kla / h [n] (h = substep
+        length) -> xs, dxs [n, n_sub + 1, 14] float64.  kind 0 control interval (ec [n]; n_sub defaults to cfg.substeps), 1 fill
+        (loading [n,14]), 2 idle, 3 settle + draw, then idle.  For trajectory export (SbrOS.trajectory(dense=True))."""
         x0 = torch.as_tensor(x0, dtype=torch.float64, device=self.device).contiguous()
         n = x0.shape[0]
-        kla, ec, span = (self._dev(v, torch.float64, (n,)) for v in (kla, ec, span))
-        xs = torch.empty((n, int(self.cfg.substeps) + 1, _capi.NX), dtype=torch.float64, device=self.device)
+        n_sub = int(self.cfg.substeps if n_sub is None else n_sub)
+        kla, h = self._dev(kla, torch.float64, (n,)), self._dev(h, torch.float64, (n,))
+        ec = self._dev(ec, torch.float64, (n,))
+        ld = self._dev(loading, torch.float64, (n, _capi.NX))
+        xs = torch.empty((n, n_sub + 1, _capi.NX), dtype=torch.float64, device=self.device)
         dxs = torch.empty_like(xs)
-        _capi.check(self.lib.sbr_eval_substeps(self._h, n, _ptr(x0), _ptr(kla), _ptr(ec), _ptr(span), _ptr(xs), _ptr(dxs),
-                                               self._stream()), self._h)
+        _capi.check(self.lib.sbr_eval_substeps(self._h, int(kind), n, n_sub, _ptr(x0), _ptr(kla), _ptr(ec), _ptr(ld), _ptr(h),
+                                               _ptr(xs), _ptr(dxs), self._stream()), self._h)
         return xs, dxs
 
     def draw_scenarios(self, seed):

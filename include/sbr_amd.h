@@ -234,15 +234,19 @@ int sbr_get_influent(sbr_env* env, double* out, void* stream);
 int sbr_eval_rhs(sbr_env* env, int32_t kind, int64_t n, const double* x, const double* kla, const double* ec,
                  const double* loading, double* dx, void* stream);
 
-/* Dense output of ONE control interval, for trajectory export: the reference returns odeint's solution on the 9- or
- * 10-point grid linspace(t, t + t_delta, int(t_delta/dt)) of every interval and appends those rows to t_t / x_t / So_t ...
- * (gym_SBR_oneshot.py:1339, :1369, :1959-1961); a fixed-step integrator has its own nodes instead.  For n independent
- * intervals given by start state x0 [n][14], the held Kla [n] and EC [n] and the interval length span [n] (days), this
- * writes the cfg.substeps + 1 RK4 nodes xs [n][substeps + 1][14] (node 0 = x0, last node = the state sbr_step ends the
- * interval in, to rounding) and the right-hand side at every node dxs [n][substeps + 1][14]: values and slopes for
- * cubic-Hermite interpolation onto any grid.  DEVICE pointers.  Not on the stepping path. */
-int sbr_eval_substeps(sbr_env* env, int64_t n, const double* x0, const double* kla, const double* ec, const double* span,
-                      double* xs, double* dxs, void* stream);
+/* Dense output of one integration span, for trajectory export: the reference returns odeint's solution on an output grid
+ * of its own - linspace(t, t + t_delta, int(t_delta/dt)) = 9 or 10 points per control interval, 252 points over the fill
+ * phase, 463 over the idle phase - and appends those rows to t_t / x_t / So_t ... (gym_SBR_oneshot.py:296-313, :1339, :1369,
+ * :1959-1961, :1122-1155); a fixed-step integrator has its own nodes instead.  For n independent spans given by start state
+ * x0 [n][14], the held Kla [n] and the substep length h [n] (days), this writes the n_sub + 1 RK4 nodes xs [n][n_sub + 1][14]
+ * (node 0 = the start state; with n_sub = cfg.substeps and h = span/n_sub the last node is the state sbr_step ends the
+ * interval in, to rounding) and the right-hand side at every node dxs [n][n_sub + 1][14]: values and slopes for cubic-Hermite
+ * interpolation onto any grid.  kind 0: a control interval (reaction_dxdt :1658-1787, ec [n] held); 1: the fill phase
+ * (filling_dxdt :1424-1583, loading [n][14] with loading[0] = the inflow); 2: the idle phase (idle_dxdt :2424-2552); 3: settle
+ * and draw (Sim_Settling_Drawing :2264-2420) applied to x0 first, then the idle phase - node 0 is the reactor after the draw.
+ * ec may be NULL unless kind == 0, loading unless kind == 1.  DEVICE pointers.  Not on the stepping path. */
+int sbr_eval_substeps(sbr_env* env, int32_t kind, int64_t n, int32_t n_sub, const double* x0, const double* kla, const double* ec,
+                      const double* loading, const double* h, double* xs, double* dxs, void* stream);
 
 /* device-side normal draws used by sbr_reset when rnd == NULL, exposed for tests: out [N][48]. */
 int sbr_draw_normals(sbr_env* env, uint64_t seed, double* out, void* stream);

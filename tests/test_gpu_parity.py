@@ -991,10 +991,12 @@ def test_reference_shaped_single_env(G):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["const_2_5", "random_a"])
 def test_dense_trajectory_on_the_reference_output_grid(G, name):
-    """trajectory(dense=True): the rows the reference appends per control interval (gym_SBR_oneshot.py:1339, :1359-1369,
-    :876-892) - t_range[1:], x_out[1:], x_out[:-1, k], len - 1 copies of the set-points - rebuilt from the RK4 nodes by cubic
-    Hermite interpolation.  Against the reference's OWN lists and LSODA rows of the golden episode: the time grid bit for bit,
-    the states inside the parity gate (closed loop: an episode the default-tolerance run can be followed on)."""
+    """trajectory(dense=True): the rows the reference appends on its own output grids - 252 over the fill phase (:296-313), per
+    control interval t_range[1:], x_out[1:], x_out[:-1, k] and len - 1 copies of the set-points (gym_SBR_oneshot.py:1339,
+    :1359-1369, :876-892), constant settle / draw rows and the idle phase on the done call (:1122-1155) - rebuilt from RK4 nodes
+    replayed on the device by cubic Hermite interpolation.  Against the reference's OWN lists and LSODA rows of the golden
+    episode: the time grid bit for bit (all 4767 entries), the states inside the parity gate (closed loop: an episode the
+    default-tolerance run can be followed on)."""
     e = golden("sbros_" + name)
     env = G.make("SBROS-v1")
     env.reset(rnd=e["rnd"])
@@ -1003,26 +1005,46 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
     per_call = env.trajectory(as_dict=True)
     d = env.trajectory(as_dict=True, dense=True)
     rows = e["iv_n_rows"]                                   # 9 or 10 output rows per interval, 466 intervals
-    n_dense = int((rows - 1).sum())
-    assert n_dense == 3994 and len(d["t_t"]) == n_dense and d["x_t"].shape == (n_dense, 14)
-    # the reference's t_t is [0] + 251 fill rows + these + the terminal phases' rows: the same doubles
-    assert np.array_equal(np.array(d["t_t"]), e["traj_t_t"][252:252 + n_dense])
+    n_dense, lo = int((rows - 1).sum()), 252                # the fill phase's 252 rows come first (:296-313)
+    n_all = int(e["traj_len_t_t"])
+    assert n_dense == 3994 and n_all == 4767 == int(e["traj_len_x_t"])
+    # the reference's whole t_t - [0] + 251 fill rows + 8 or 9 per interval + settle, draw and idle rows: the same doubles
+    assert len(d["t_t"]) == n_all and np.array_equal(np.array(d["t_t"]), e["traj_t_t"])
+    assert d["x_t"].shape == (n_all, 14) and len(d["u_DO_t"]) == n_all and len(d["u_EC_t"]) == n_all
+    assert np.array_equal(np.array(d["t_t"][lo:lo + n_dense]), np.concatenate([e["iv_t_rows"][i, 1:rows[i]] for i in range(466)]))
+    # control intervals against the reference's LSODA rows
     ref_rows = np.vstack([e["iv_x_rows"][i, 1:rows[i]] for i in range(466)])
-    assert np.array_equal(np.array(d["t_t"]), np.concatenate([e["iv_t_rows"][i, 1:rows[i]] for i in range(466)]))
-    g = gate(d["x_t"], ref_rows)
+    g = gate(d["x_t"][lo:lo + n_dense], ref_rows)
+    print("dense rows of %s: worst gate %.3f over %d rows" % (name, g.max(), n_dense))
     assert g.max() <= 1.0, g.max()
-    # the concentration lists take x_out[:-1]: start row in, end row out; the reference's own lists (after the 251 fill rows)
+    # fill phase: starts at x0_init, ends in the post-fill state; done call: ends in the state after idle
+    assert np.array_equal(d["x_t"][0], e["x0_init"]) and gate(d["x_t"][lo - 1], e["x_postfill"]).max() <= 1.0
+    assert gate(d["x_t"][-1], e["term_x_after_idle"]).max() <= 1.0
+    assert gate(d["x_t"][lo + n_dense + 47], e["term_x_pre_settle"]).max() <= 1.0        # the 48 settle rows hold the pre-settle state
+    assert gate(d["x_t"][lo + n_dense + 48], e["term_x_after_draw"]).max() <= 1.0        # the 11 draw rows the drawn reactor
+    # the concentration lists take x_out[:-1] (start row in, end row out): the reference's own lists, all 4766 entries
     for key, j, scale in (("So_t", 8, 8.0), ("Sno_t", 9, 20.0), ("Snh_t", 10, 20.0)):
-        ref = e["traj_" + key][251:251 + n_dense]
-        assert len(d[key]) == n_dense and (np.abs(np.array(d[key]) - ref) <= 1e-5 * np.abs(ref) + 1e-5 * scale).all(), key
-    assert np.allclose(np.array(d["Ss_t"]), np.concatenate([[env._x_postfill[2]], d["x_t"][:-1, 2]]), rtol=1e-12, atol=0)
+        ref = e["traj_" + key]
+        assert len(d[key]) == len(ref) == n_all - 1
+        assert (np.abs(np.array(d[key]) - ref) <= 1e-5 * np.abs(ref) + 1e-5 * scale).all(), key
+    assert len(d["Ss_t"]) == n_all - 1
     # set-points: len - 1 copies per interval of what was in force in THAT interval (both intervals of a boundary call)
-    assert np.array_equal(np.array(d["u_DO_t"]), np.repeat(e["iv_u_DO"], rows - 1))
-    assert np.array_equal(np.array(d["u_EC_t"]), np.repeat(e["iv_u_EC"], rows - 1))
+    assert np.array_equal(np.array(d["u_DO_t"][lo:lo + n_dense]), np.repeat(e["iv_u_DO"], rows - 1))
+    assert np.array_equal(np.array(d["u_EC_t"][lo:lo + n_dense]), np.repeat(e["iv_u_EC"], rows - 1))
+    assert set(d["u_DO_t"][lo + n_dense:]) == {d["u_DO_t"][lo + n_dense - 1]} and not any(d["u_DO_t"][:lo])   # Kla = 0 during the fill
     # the last row of a call's last interval is the state step() returned (the per-call record), to rounding
-    ends = np.cumsum(rows - 1)[np.searchsorted(e["iv_call"], np.arange(463), side="right") - 1] - 1
+    ends = lo + np.cumsum(rows - 1)[np.searchsorted(e["iv_call"], np.arange(463), side="right") - 1] - 1
     rel = np.abs(d["x_t"][ends[:462]] - per_call["x_t"][:462]) / (np.abs(per_call["x_t"][:462]) + 1e-9)
     assert rel.max() < 1e-12, rel.max()
+    rel = np.abs(d["x_t"][-1] - per_call["x_t"][462]) / (np.abs(per_call["x_t"][462]) + 1e-9)      # ... and of the done call, after idle
+    assert rel.max() < 1e-9, rel.max()
+    # a running episode: dense rows exist from the first call on
+    env2 = G.make("SBROS-v1")
+    env2.reset(rnd=e["rnd"])
+    assert len(env2.trajectory(as_dict=True, dense=True)["t_t"]) == 252
+    env2.step(e["actions"][0])
+    assert len(env2.trajectory(as_dict=True, dense=True)["t_t"]) == 252 + int(rows[0]) - 1
+    env2.close()
     # the lists that are per call upstream too are untouched by dense=True
     assert np.array_equal(d["reward_t"], per_call["reward_t"]) and len(d["EC"]) == 463
     env.close()
