@@ -351,13 +351,6 @@ def main():
     reset()
     end_of_episode()
     reset()
-    t_prime = time.perf_counter()
-    while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
-        run(CALLS_PER_EPISODE, record=False)
-        torch.cuda.synchronize(dev)
-    if state["in_episode"] == CALLS_PER_EPISODE:              # warm-up and timing start at the first call of an episode
-        end_of_episode()
-        reset()
     # HIP events for the device time of the step launches.  torch creates an event at its first record(), and the first
     # timed record of a process costs 30-45 us on top (scripts/probes/sync_wait.py, profiles/r02_sync_wait.log): the warm-up
     # steps go through the same recording code path and every event of the pool is recorded once, so that the timed region
@@ -366,8 +359,20 @@ def main():
                   for _ in range(2 * (args.steps // CALLS_PER_EPISODE + args.warmup // CALLS_PER_EPISODE + 6))]
     for ev in event_pool:
         ev.record()
+    # The collector runs HERE, before the clocks are primed, and stays off until the timed region is over: a collection of a
+    # torch process takes tens of milliseconds of host time during which the GPU idles and drops out of its steady clocks
+    # (round 3, scripts/probes/rollout_sustained.py: the first 25 ms after such a gap run up to 24 % slower) - placed between
+    # priming and timing, as it was, it undid the priming for every region shorter than ~30 ms.
+    gc.collect(); gc.disable()
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
+        run(CALLS_PER_EPISODE, record=False)
+        torch.cuda.synchronize(dev)
+    t_primed = time.perf_counter()
+    if state["in_episode"] == CALLS_PER_EPISODE:              # warm-up and timing start at the first call of an episode
+        end_of_episode()
+        reset()
     run(max(args.warmup - 1, 0), record=True)
-    gc.collect(); gc.disable()                  # no collector pause of the host inside a region that may be 300 us long
     # opening bracket: synchronise, barrier, the last warm-up step, synchronise (see the module docstring)
     torch.cuda.synchronize(dev)
     if world > 1 or force_dist:
@@ -378,6 +383,7 @@ def main():
     acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0, allgathers=0)
     episodes_before = state["episode"]
     t0 = time.perf_counter()
+    gap_ms = (t0 - t_primed) * 1e3              # (diagnostic) host time between the end of clock priming and the timed region
     run(args.steps, record=True)
     if dist_up and acct["allgathers"] == 0:     # no episode boundary fell into the K steps: the collective of the path still
         end_of_episode()                        # runs once inside the timed region of an N > 1 run (returns so far)
@@ -476,7 +482,8 @@ def main():
                      "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
                      "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
-                                         "host_in_reset_issue": acct["reset_issue_ms"]},
+                                         "host_in_reset_issue": acct["reset_issue_ms"],
+                                         "since_clock_priming": gap_ms},
                      "fp64_valu": fp64,
                      "headline": "fp64_valu" if fused else "hbm",
                      "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
