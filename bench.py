@@ -364,6 +364,8 @@ def main():
     # (round 3, scripts/probes/rollout_sustained.py: the first 25 ms after such a gap run up to 24 % slower) - placed between
     # priming and timing, as it was, it undid the priming for every region shorter than ~30 ms.
     gc.collect(); gc.disable()
+    if dist_up:                                 # the first barrier of a process group is slow (lazy connection set-up): not
+        fence()                                 # between priming and timing either
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
         run(CALLS_PER_EPISODE, record=False)
