@@ -880,6 +880,44 @@ def test_cycle_env_sbr_v2_against_oracle_and_reference(G, tables):
     e1.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_cycle_env_with_perturbed_constants_and_phase_schedule(G, tables, seed):
+    """SBR-v2 with constants drawn within +-20 % of their defaults, the PHASE LENGTHS included: the kernel takes the number of
+    control intervals of each phase, linspace's step and the reward's 1/(n td) from the host (derive_params, with the
+    reference's own IEEE operations), the oracle forms them per call like the reference does (sub_phases_FB.py:183-184) - they
+    must agree for any schedule, not just the default one."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 96
+    rs = np.random.RandomState(seed)
+    cfg, p = _capi.default_config(), O.default_params()
+    for name in PERTURBED + ["cyc_Kc", "cyc_tauI", "cyc_tauD"]:
+        v = getattr(cfg, name) * rs.uniform(0.8, 1.2)
+        setattr(cfg, name, v); setattr(p, name, v)
+    ratios = np.array(list(cfg.t_ratio)) * rs.uniform(0.8, 1.2, 8)
+    for k in range(8):
+        cfg.t_ratio[k] = p.t_ratio[k] = float(ratios[k])
+    scen = (np.arange(n) % 8).astype(np.int32)
+    z = rs.randn(n, 48)
+    a = rs.uniform(0.0, 0.4, (n, 3))
+    env = G.SbrEnv2Vec(n, out_dtype=torch.float64, action_dtype=torch.float64, config=cfg)
+    ora = O.OracleCycleBatch(n, params=p, nthreads=8)
+    infl = O.OracleBatch(n, params=p).mix(means, stds, scen, z)
+    assert np.abs(_np(env.reset(scenario=scen, rnd=z)) - ora.reset(infl)).max() < 1e-9
+    obs, rew, _ = env.step(torch.from_numpy(a).cuda())
+    ost, orew, odiag = ora.step(a)
+    x, ctrl = env.get_state()
+    clean = (_np(ctrl)[_capi.C_STATUS].astype(int) & _capi.ST_NEAR_POLE) == 0
+    g = gate(_np(x).T[clean], ora.x[clean]).max()
+    print("per-cycle env, perturbed constants and schedule, seed %d: %d of %d envs clear of the poles, worst gate %.3e" % (seed, clean.sum(), n, g))
+    assert clean.sum() > n // 2 and g < 1e-6
+    assert np.allclose(_np(rew)[clean], orew[clean], rtol=1e-9, atol=1e-9) and np.allclose(_np(obs)[clean], ost[clean], rtol=1e-9, atol=1e-9)
+    # the mean Kla of the three aerated phases and Xf: the interval counts n of the schedule enter here (sum(Kla)/n)
+    assert np.allclose(_np(env.diag)[clean], odiag[clean], rtol=1e-9, atol=1e-11)
+    env.close()
+
+
 def _sharded_worker(rank, world, n_global, port, out_dir):
     import os
     import torch.distributed as dist
@@ -1139,6 +1177,62 @@ def test_other_substep_counts_against_oracle(G, tables, substeps):
         assert np.abs(_np(r) - orr).max() < 1e-12 and np.abs(_np(o) - oo).max() < 1e-10
         assert np.array_equal(_np(ctrl)[_capi.C_T], ora.envs["t"])
     assert float(_np(ctrl)[_capi.C_T].min()) > 0.0641667            # the run crossed into the aerobic phase
+    env.close()
+
+
+PERTURBED = ("Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka So_sat Kla_max Kc_DO tauI_DO EC_max Kc_EC tauI_EC "
+             "EC_conc act_DO_max act_EC_max biomass_setpoint settler_vmax").split()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_perturbed_model_constants_and_derivative_action_against_oracle(G, tables, seed):
+    """Every constant of the model is a parameter of the C ABI, and the kernels do not use them as the reference writes them:
+    mu_H, mu_A, k_h and eta_g K_OH are folded into the Monod denominators, b_H and 1/Y_A into step coefficients, the
+    stoichiometric products are formed on the host (sbr_rates, derive_params).  That algebra must hold for ANY constants, not
+    just the defaults all other tests run with: 31 kinetic, stoichiometric, controller and settler constants are drawn within
+    +-20 % of their defaults, and both PIDs get a non-zero derivative time - tau_D = 0 upstream (:85, :94), so the So[-2] /
+    Sno[-2] rows and the derivative terms (:1892, :1898-1902, :2016-2025) are otherwise never exercised.  A whole episode in
+    lockstep with the oracle (re-synchronised to the device state before every call), terminal phases included."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 128
+    rs = np.random.RandomState(seed)
+    cfg, p = _capi.default_config(), O.default_params()
+    for name in PERTURBED:
+        v = getattr(cfg, name) * rs.uniform(0.8, 1.2)
+        setattr(cfg, name, v); setattr(p, name, v)
+    for name, v in (("tauD_DO", 2e-5 * rs.uniform(0.5, 1.5)), ("tauD_EC", 1e-8 * rs.uniform(0.5, 1.5))):
+        setattr(cfg, name, v); setattr(p, name, v)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64, config=cfg)
+    ora = O.OracleBatch(n, params=p)
+    scen = (np.arange(n) % 8).astype(np.int32)
+    rnd = rs.randn(n, 48)
+    obs = _np(env.reset(scenario=scen, rnd=rnd)).copy()
+    assert np.abs(obs - ora.reset(ora.mix(means, stds, scen, rnd))).max() < 1e-10
+    x, ctrl = env.get_state()
+    assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6                    # the fill phase under the perturbed constants
+    worst, d_term = 0.0, 0
+    for c in range(463):
+        a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)])
+        x, ctrl = env.get_state()
+        ora.load_state(_np(x), _np(ctrl))
+        o, s_, r, d = env.step(torch.from_numpy(a).cuda())
+        oo, os_, orr, od = ora.step(a)
+        x, ctrl = env.get_state()
+        ctrl = _np(ctrl)
+        g = gate(_np(x).T, ora.envs["x"]).max()
+        worst = max(worst, g)
+        assert g < 1e-6 and np.array_equal(_np(d), od), (c, g)
+        assert np.abs(_np(r) - orr).max() < 1e-11 and np.abs(_np(o) - oo).max() < 1e-9 and np.abs(_np(s_) - os_).max() < 1e-9
+        assert np.array_equal(ctrl[_capi.C_T], ora.envs["t"])
+        # both controllers' memories, derivative inputs included
+        for row, key in ((_capi.C_SO_M1, "so_m1"), (_capi.C_SO_M2, "so_m2"), (_capi.C_SNO_M1, "sno_m1"), (_capi.C_SNO_M2, "sno_m2"),
+                         (_capi.C_IE_DO, "ie_do"), (_capi.C_IE_EC, "ie_ec"), (_capi.C_EC_LAST, "ec_last"), (_capi.C_KLA_LAST, "kla_last")):
+            assert np.allclose(ctrl[row], ora.envs[key], rtol=1e-9, atol=1e-12), (c, key)
+        d_term += int(od.all())
+    assert d_term == 1 and np.all(ctrl[_capi.C_DONE] == 1) and np.abs(ctrl[_capi.C_QW] / ora.envs["qw"] - 1).max() < 1e-9
+    print("perturbed constants, seed %d: lockstep worst gate %.3e" % (seed, worst))
     env.close()
 
 
