@@ -1180,6 +1180,35 @@ def test_other_substep_counts_against_oracle(G, tables, substeps):
     env.close()
 
 
+@pytest.mark.gpu
+def test_c_abi_from_plain_c_without_python_or_torch(G, tmp_path):
+    """The drop-in boundary is a C ABI: examples/c_abi_demo.c (C99, gcc, the HIP runtime's C API for device memory) runs the
+    reference's own default episode - scenario 6, numpy seed 0, action [2.0, 5.0] - through libsbr_amd.so in a process that
+    contains neither Python nor torch, and prints the numbers SURVEY.md 8c lists as anchors.  Compared with the reference's."""
+    import shutil, subprocess
+    from conftest import ROOT
+    from gym_sbr2_amd import build as B
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.dirname(B.LIB)
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", libdir, "-lsbr_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    out = dict(line.split() for line in p.stdout.strip().splitlines())
+    e = golden("sbros_const_2_5")
+    assert int(out["calls"]) == 463
+    for k, call in (("reward[1]", 0), ("reward[2]", 1), ("reward[100]", 99)):
+        assert abs(float(out[k]) - e["step_reward"][call]) < 5e-7, k              # -0.005341505578026706, 0.0005042630758199245 upstream
+    assert abs(float(out["Kla[100]"]) - e["step_Kla"][99]) < 3e-3                 # 160.969686931186
+    assert abs(float(out["So[100]"]) - e["step_x_end"][99][8]) < 1e-5 * (abs(e["step_x_end"][99][8]) + 8.0)   # 2.0044944036975214
+    assert abs(float(out["return"]) / float(e["episode_return"]) - 1) < 1e-5      # -0.8789670883455737
+    assert abs(float(out["return_row"]) - float(out["return"])) < 1e-12
+    assert abs(float(out["Qw"]) / float(e["term_Qw"]) - 1) < 1e-5                 # 0.05015591126665638
+
+
 PERTURBED = ("Ya Yh fp ixb ixp muH Ks Koh Kno bH eta_g eta_h kh Kx muA Knh bA Koa ka So_sat Kla_max Kc_DO tauI_DO EC_max Kc_EC tauI_EC "
              "EC_conc act_DO_max act_EC_max biomass_setpoint settler_vmax").split()
 
