@@ -1,4 +1,4 @@
-"""Distils gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/:
+"""Distils gpurun_out/<tag>/ (written by scripts/profile_round.sh, which also runs this on the GPU box) into profiles/:
     <tag>_bench_<workload>.json, <tag>_bench_config2_kernel_stats.csv, <tag>_pmc_{fetch,write,sq}_by_kernel.csv,
     <tag>_pmc_traffic.json  (HBM bytes per k_step launch, read by bench.py as roofline.traffic)
 Unit handling as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counter values are KiB; WRITE_SIZE is exact; on gfx950

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Profiling recipe of a round, to be run ON THE GPU BOX (inside one gpurun call):
-#   gpurun --timeout 900 -- 'bash scripts/profile_round.sh r01'
-# Writes everything under gpurun_out/<tag>/; scripts/pmc_summarise.py then distils it into profiles/.
-# Separate passes on purpose: --kernel-trace --stats for durations; one --pmc pass per counter (FETCH_SIZE, WRITE_SIZE),
-# each only with --kernel-trace; the SQ pass last.  python3 is the program directly after `--`.
+#   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh r03'        then here:  cp gpurun_out/r03/profiles/* profiles/
+# Writes everything under gpurun_out/<tag>/; scripts/pmc_summarise.py (run on the box, it needs no GPU) distils the passes
+# into profiles/<tag>_*, and the bench lines are taken LAST, so that their roofline.traffic can quote the PMC summary of this
+# very library (bench.py matches it by source hash).  Separate passes on purpose: --kernel-trace --stats for durations; one
+# --pmc pass per counter (FETCH_SIZE, WRITE_SIZE), each only with --kernel-trace; the SQ pass last.  python3 is the program
+# directly after `--`.
 set -e -o pipefail
 tag=${1:-r01}
 out=gpurun_out/$tag
@@ -12,10 +14,6 @@ mkdir -p $out
 # a committed profile only to a library with the same hash)
 python3 -c "from gym_sbr2_amd import build as b; b.build_library(); print(open(b.HASH).read().strip())" > $out/library_source_hash.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-for w in config2 config1 config5 cycle; do
-  timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
-  echo "bench $w: $(cut -c1-160 $out/bench_$w.json)"
-done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_config2 -o run --output-format csv -- python3 bench.py --no-cpu-baseline > $out/bench_config2_profiled.json 2> $out/rocprof_trace.err
 echo "kernel trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_fetch -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_fetch.json 2> $out/pmc_fetch.err
@@ -23,4 +21,14 @@ echo "FETCH_SIZE pass done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pmc_write -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_write.json 2> $out/pmc_write.err
 echo "WRITE_SIZE pass done"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace -d $out/pmc_sq -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_sq.json 2> $out/pmc_sq.err || echo "SQ pass failed (optional)"
+python3 scripts/pmc_summarise.py $tag
+for w in config2 config1 config5 cycle; do
+  timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
+  cp $out/bench_$w.json profiles/${tag}_bench_$w.json
+  echo "bench $w: $(cut -c1-160 $out/bench_$w.json)"
+done
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_config2_driver_style.json 2> $out/bench_driver.err
+cp $out/bench_config2_driver_style.json profiles/${tag}_bench_config2_driver_style.json
+echo "bench driver-style: $(cut -c1-160 $out/bench_config2_driver_style.json)"
+mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/
 echo "profile_round $tag finished"
