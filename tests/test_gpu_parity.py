@@ -1380,16 +1380,22 @@ def test_output_rows_to_misaligned_destinations(G):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force_dist", [False, True])
+@pytest.mark.parametrize("force_dist", [False, True, "launcher"])
 def test_bench_line_contract(force_dist):
     """bench.py as the driver runs it (`--gpus 1 --steps 20 --warmup 5`), in its own process; with force_dist the process group,
-    the barrier of the bracket and the all-gather run over RCCL with one rank (what every rank of an N > 1 run executes).
+    the barrier of the bracket and the all-gather run over RCCL with one rank (what every rank of an N > 1 run executes);
+    "launcher": the same under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1`, the
+    driver's command line for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher's environment).
     Checks the ONE JSON line: the contract's keys, value = envs * K / wall, the event-timed launch inside the wall time."""
     import json, os, subprocess, sys
     from conftest import ROOT
     env = dict(os.environ, SBR_BENCH_FORCE_DIST="1" if force_dist else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+    if force_dist == "launcher":
+        args = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29541"] + args
+        env.pop("MASTER_PORT")
+    p = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
