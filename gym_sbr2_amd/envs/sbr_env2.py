@@ -36,8 +36,8 @@ class SbrEnv2(_gym.Env):
                  "Kla8_mean", "Xf"]
         return dict(zip(names, self._vec.diag[0].tolist()))
 
-    def render(self, mode="human"):
-        return None
+    def render(self, mode="human", close=False):
+        print("Reward for this episode: {}".format(self.reward))      # gym_SBR_env2.py:189-192
 
     def close(self):
         self._vec.close()
