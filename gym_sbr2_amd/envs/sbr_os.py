@@ -236,6 +236,7 @@ class SbrOS(_gym.Env):
         from .. import _capi as K
         n = len(self._rewards)
         rec = self._trace[:n].cpu().numpy()[:, :, 0]
+        rec = rec[np.isfinite(rec[:, K.TR_T])]          # calls made after `done` leave no record (a finished env ignores them)
         x_t = rec[:, K.TR_X0:K.TR_X0 + 14]
         cols = {"t_t": rec[:, K.TR_T], "x_t": x_t, "u_DO_t": rec[:, K.TR_U_DO], "u_EC_t": rec[:, K.TR_U_EC],
                 "state_t": [s.copy() for s in self._states], "So_t": x_t[:, 8], "Ss_t": x_t[:, 2], "EC": rec[:, K.TR_EC],

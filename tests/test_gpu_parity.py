@@ -1083,6 +1083,19 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
     env2.step(e["actions"][0])
     assert len(env2.trajectory(as_dict=True, dense=True)["t_t"]) == 252 + int(rows[0]) - 1
     env2.close()
+    # calls after `done` are ignored by a finished env and leave no rows; a carried-over second cycle fills from where the first
+    # one ended (its dense rows start at that state and pass through the new post-fill state)
+    env.step(e["actions"][0])
+    assert len(env.trajectory(as_dict=True, dense=True)["t_t"]) == n_all
+    x_end = per_call["x_t"][462].copy()                  # the state the done call left on the device
+    env.reset(rnd=e["rnd"], carry_over=True)
+    for k in range(3):
+        env.step(e["actions"][k])
+    d2 = env.trajectory(as_dict=True, dense=True)
+    assert np.array_equal(d2["x_t"][0], x_end)
+    assert np.allclose(d2["x_t"][251], env._x_postfill, rtol=1e-9, atol=1e-12)       # the replayed fill ends where the device's did
+    assert abs(d2["x_t"][251][0] - 1.32) < 1e-12 and len(d2["t_t"]) == 252 + int((rows[:3] - 1).sum())
+    assert np.abs(d2["x_t"][-1] - env.trajectory(as_dict=True)["x_t"][2]).max() < 1e-9
     # the lists that are per call upstream too are untouched by dense=True
     assert np.array_equal(d["reward_t"], per_call["reward_t"]) and len(d["EC"]) == 463
     env.close()
