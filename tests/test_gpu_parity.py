@@ -64,6 +64,17 @@ def test_native_library_is_loaded_and_fails_loudly_on_bad_config(G):
     assert lib.sbr_get_ctrl_row(env._h, _capi.NCTRL, out.data_ptr(), None) == -1
     assert lib.sbr_get_ctrl_row(env._h, -1, out.data_ptr(), None) == -1
     assert lib.sbr_rollout(env._h, -3, 0, None, None, None) == -1
+    # sbr_eval_substeps: kinds 0..3 only, a control interval needs ec, the fill phase its loading vector, n_sub >= 1
+    x0, v = torch.ones(4, 14, dtype=torch.float64, device="cuda"), torch.ones(4, dtype=torch.float64, device="cuda")
+    xs = torch.empty(4, 11, 14, dtype=torch.float64, device="cuda"); dxs = torch.empty_like(xs)
+    P = lambda t: t.data_ptr()                                    # noqa: E731
+    assert lib.sbr_eval_substeps(env._h, 0, 4, 10, P(x0), P(v), P(v), None, P(v), P(xs), P(dxs), None) == 0
+    assert lib.sbr_eval_substeps(env._h, 4, 4, 10, P(x0), P(v), P(v), None, P(v), P(xs), P(dxs), None) == -1
+    assert lib.sbr_eval_substeps(env._h, 0, 4, 10, P(x0), P(v), None, None, P(v), P(xs), P(dxs), None) == -1
+    assert lib.sbr_eval_substeps(env._h, 1, 4, 10, P(x0), P(v), None, None, P(v), P(xs), P(dxs), None) == -1
+    assert lib.sbr_eval_substeps(env._h, 2, 4, 0, P(x0), P(v), None, None, P(v), P(xs), P(dxs), None) == -1
+    assert b"sbr_eval_substeps" in lib.sbr_last_error(env._h)
+    torch.cuda.synchronize()
     # scenario ids outside 0..7 are clamped, never used as an index
     z = np.zeros((4, 48))
     env.reset(scenario=np.array([-5, 0, 7, 100], dtype=np.int32), rnd=z)
