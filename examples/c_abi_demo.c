@@ -52,6 +52,7 @@ int main(void) {
     double ret = 0.0;
     for (;;) {
         CHECK_SBR(sbr_step(env, d_act, d_obs, d_state, d_reward, d_done, NULL));
+        CHECK_SBR(sbr_synchronize(env, NULL));
         CHECK_HIP(hipMemcpy(h_reward, d_reward, sizeof h_reward, hipMemcpyDeviceToHost));
         CHECK_HIP(hipMemcpy(h_done, d_done, sizeof h_done, hipMemcpyDeviceToHost));
         ++calls;

@@ -70,6 +70,7 @@ SYMBOLS = {
     "sbr_eval_substeps": (C.c_int, [_VP, _I32, _I64, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_draw_normals": (C.c_int, [_VP, _U64, _VP, _VP]),
     "sbr_draw_scenarios": (C.c_int, [_VP, _U64, _VP, _VP]),
+    "sbr_synchronize": (C.c_int, [_VP, _VP]),
     "sbr_timer_start": (C.c_int, [_VP, _VP]),
     "sbr_timer_stop": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
 }

@@ -1277,6 +1277,13 @@ int sbr_draw_scenarios(sbr_env* e, uint64_t seed, int32_t* out, void* stream) {
 int sbr_set_stamps(sbr_env* e, unsigned long long* buf) { if (!e) return SBR_ERR_INVALID; e->buf.stamps = buf; return SBR_OK; }
 #endif
 
+int sbr_synchronize(sbr_env* e, void* stream) {
+    if (!e) return SBR_ERR_INVALID;
+    ON_DEVICE(e);
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    return SBR_OK;
+}
+
 int sbr_timer_start(sbr_env* e, void* stream) {
     if (!e) return SBR_ERR_INVALID;
     ON_DEVICE(e);

@@ -17,8 +17,9 @@ sampled once per step() call (see its docstring).
 import numpy as np
 import torch
 
+from .. import _capi
 from .. import _gymcompat as _gym
-from ..vec_env import SbrOSVec
+from ..vec_env import SbrOSVec, _raw_stream
 
 _Box = _gym._Box          # (kept for callers that imported the stand-in from here)
 
@@ -51,7 +52,9 @@ class SbrOS(_gym.Env):
         self.observation_space = _gym.box(np.full(18, -np.inf), np.full(18, np.inf))
         # reward: None / "eqi_oci" = the reference's (module_reward_EQIOCI.py); "g2anet", "oci" = the other reward modules
         self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64, reward=reward)
-        self._vec.enable_host_io()        # the kernel reads the action from, and writes its outputs to, pinned host memory
+        views = self._vec.enable_host_io()        # the kernel reads the action from, and writes its outputs to, pinned host memory
+        self._act_row, self._obs_row, self._state_row = views[0][0], views[1][0], views[2][0]
+        self._reward_view, self._done_view = views[3], views[4]
         self._seed = seed
         self._episodes = 0
         self._rewards, self._states, self._actions = [], [], []
@@ -84,13 +87,19 @@ class SbrOS(_gym.Env):
         return self._split(obs[0].cpu())
 
     def step(self, action):
-        obs, state, reward, done = self._vec.step_host([[float(action[0]), float(action[1])]])
-        state = state[0].copy()
-        reward, done = float(reward[0]), bool(done[0])
+        v = self._vec
+        self._act_row[0] = action[0]; self._act_row[1] = action[1]        # pinned host memory the kernel reads directly
+        st = _raw_stream(v.device.index)
+        rc = v._sbr_step(v._h, *v._h_ptrs, st) or v._sbr_sync(v._h, st)   # two C calls: launch, wait
+        if rc:
+            _capi.check(rc, v._h)
+        o = self._obs_row.tolist()
+        state = self._state_row.copy()
+        reward, done = float(self._reward_view[0]), bool(self._done_view[0])
         self._rewards.append(reward)
         self._states.append(state)
         self._actions.append((float(action[0]), float(action[1])))
-        return self._split(obs[0]), state, reward, done, {}
+        return (o[:9], o[9:]), state, reward, done, {}
 
     def get_available_actions(self, pre_action, n_agents, n_action):
         """Mask of the discrete set-point moves that stay inside the action bounds (:440-459)."""

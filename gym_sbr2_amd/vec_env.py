@@ -166,19 +166,20 @@ class SbrOSVec:
         self._h_done = torch.empty((n,), dtype=torch.uint8).pin_memory()
         self._h_views = (self._h_act.numpy(), self._h_obs.numpy(), self._h_state.numpy(), self._h_reward.numpy(),
                          self._h_done.numpy())
+        self._h_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._h_act, self._h_obs, self._h_state, self._h_reward, self._h_done))
+        self._sbr_sync = self.lib.sbr_synchronize
         return self._h_views
 
     def step_host(self, action):
         """step() through the pinned host buffers of enable_host_io(): action is array-like [N,2]; returns numpy views of
-        obs, state, reward, done, valid until the next call (the stream has been synchronised)."""
-        act, obs, state, reward, done = self._h_views
-        act[...] = action
-        st = torch.cuda.current_stream(self.device)
-        _capi.check(self.lib.sbr_step(self._h, C.c_void_p(self._h_act.data_ptr()), C.c_void_p(self._h_obs.data_ptr()),
-                                      C.c_void_p(self._h_state.data_ptr()), C.c_void_p(self._h_reward.data_ptr()),
-                                      C.c_void_p(self._h_done.data_ptr()), C.c_void_p(st.cuda_stream)), self._h)
-        st.synchronize()
-        return obs, state, reward, done
+        obs, state, reward, done, valid until the next call (the stream has been synchronised).  Two C calls - sbr_step and
+        sbr_synchronize - with every pointer converted once in enable_host_io()."""
+        self._h_views[0][...] = action
+        st = _raw_stream(self.device.index)
+        rc = self._sbr_step(self._h, *self._h_ptrs, st) or self._sbr_sync(self._h, st)
+        if rc:
+            _capi.check(rc, self._h)
+        return self._h_views[1:]
 
     def capture_steps(self, actions):
         """Capture one step() per action tensor of `actions` (a sequence of [N,2] device tensors at fixed addresses) into a

@@ -255,6 +255,11 @@ int sbr_draw_normals(sbr_env* env, uint64_t seed, double* out, void* stream);
  * pointer (replaces np.random.choice(8, 1), gym_SBR_env4.py:107). */
 int sbr_draw_scenarios(sbr_env* env, uint64_t seed, int32_t* out, void* stream);
 
+/* Block the calling host thread until everything queued on `stream` has finished (hipStreamSynchronize on the handle's
+ * device).  For host-driven callers: the reference's step() returns finished numbers, so the reference-shaped single env
+ * reads its pinned-host outputs after sbr_step + sbr_synchronize - two C calls per step, no other runtime binding needed. */
+int sbr_synchronize(sbr_env* env, void* stream);
+
 /* timing helper for bench.py: average device time (ms) per sbr_step launch between two marks,
  * measured with HIP events on `stream` (the stream the kernels are launched on). */
 int sbr_timer_start(sbr_env* env, void* stream);
