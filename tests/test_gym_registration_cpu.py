@@ -102,3 +102,25 @@ def test_a_failed_registration_is_reported_not_swallowed(fresh_package):
     assert any(issubclass(x.category, RuntimeWarning) and "SBROS-v1" in str(x.message) for x in w)
     with pytest.raises(RuntimeError, match="SBROS-v1"):
         registration.register_with_gym(strict=True)
+
+
+def test_opt_in_alias_for_code_written_against_the_reference_package(fresh_package, monkeypatch):
+    """`import gym_SBR` / `from gym_SBR.envs import SbrOS` (gym_SBR/__init__.py, gym_SBR/envs/__init__.py) resolve to this package
+    after gym_sbr2_amd.compat.install_as_gym_SBR() - opt-in, and never over a gym_SBR that is already imported."""
+    mods = _stand_in("gym")
+    compat_mod, envs = fresh_package(mods)
+    for name in ("gym_SBR", "gym_SBR.envs"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    from gym_sbr2_amd import compat
+    pkg = compat.install_as_gym_SBR()
+    import gym_SBR
+    from gym_SBR.envs import SbrEnv2, SbrOS
+    assert gym_SBR is pkg and SbrOS is envs.SbrOS and SbrEnv2 is envs.SbrEnv2 and gym_SBR.REGISTERED_WITH == {"gym": ["SBR-v2", "SBROS-v1"]}
+    assert set(mods["gym.envs.registration"].registry) == {"SBROS-v1", "SBR-v2"}
+    assert compat.install_as_gym_SBR() is not None                       # re-installing the alias over itself is fine
+    monkeypatch.setitem(sys.modules, "gym_SBR", types.ModuleType("gym_SBR"))      # ... but not over somebody else's gym_SBR
+    with pytest.raises(RuntimeError):
+        compat.install_as_gym_SBR()
+    assert compat.install_as_gym_SBR(force=True).__sbr_amd_alias__
+    for name in ("gym_SBR", "gym_SBR.envs"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
