@@ -263,18 +263,29 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU: rank r drives device LOCAL_RANK.  SBR_BENCH_BACKEND=gloo is a REHEARSAL mode for a box with fewer
+    # GPUs than ranks (tests/test_gpu_parity.py: two ranks on the one GPU of a test box): ranks then share devices
+    # (LOCAL_RANK modulo the device count) and the collectives go through gloo, because RCCL refuses two ranks on one device.
+    # It exercises everything an N > 1 run does except RCCL itself and is labelled in the JSON line; the driver never sets it.
+    backend = os.environ.get("SBR_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("SBR_BENCH_BACKEND must be nccl (RCCL) or gloo (rehearsal)")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     force_dist = os.environ.get("SBR_BENCH_FORCE_DIST") == "1"      # rehearse the RCCL calls with a single rank
     if world > 1 or force_dist:
         if force_dist and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif backend == "gloo":
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)    # nccl == RCCL on ROCm
 
     if args.workload == "cycle":
-        return bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit)
+        return bench_cycle(args, torch, dist, world, rank, dev_index, dev, emit)
     n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
     n_global = n_local * world
     physical = args.policy == "physical"
@@ -282,7 +293,7 @@ def main():
     cfg = _capi.default_config()
     cfg.act_DO_max = do_max               # what the fused rollout's on-device policy draws from (and clips to)
     # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK
-    sh = ShardedSbrOS(n_global, rank=rank, world=world, out_dtype=torch.float32, config=cfg)
+    sh = ShardedSbrOS(n_global, rank=rank, world=world, device=dev_index, out_dtype=torch.float32, config=cfg)
     env, first = sh.env, sh.start
     assert env.num_envs == n_local and env.device == dev, (env.num_envs, env.device, dev)
     gid = torch.arange(first, first + n_local, device=dev)
@@ -469,6 +480,8 @@ def main():
         "config": {"workload": workload,
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
                    "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
+                   "collective_backend": ("none" if not dist_up else "nccl (RCCL)" if backend == "nccl" else
+                                          "gloo - REHEARSAL: %d ranks share %d GPU(s), not a scaling measurement" % (world, ndev)),
                    "allgathers_in_timed_region": acct["allgathers"],
                    "allgather_bytes_per_rank": 4 * n_local if dist_up else 0,
                    "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",

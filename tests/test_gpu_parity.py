@@ -1448,3 +1448,29 @@ def test_bench_line_contract(force_dist):
     # PMC traffic is a committed constant: present only if profiles/ holds a profile of THIS library (same source hash)
     assert (r["traffic"] is None) or ("committed constant" in r["traffic_unit"] and r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"])
     assert r["traffic"] is not None or r["traffic_unit"]
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_rehearsed_on_one_gpu():
+    """The N > 1 code path of bench.py with a real world size of 2: `python -m torch.distributed.run --nproc-per-node 2 ...
+    bench.py --gpus 2` (the driver's command line), both ranks on the one GPU of this box, collectives over gloo
+    (SBR_BENCH_BACKEND=gloo - RCCL refuses two ranks on one device).  Everything but RCCL itself runs as in a scaling run: two
+    shards by global env id, the barriers of the bracket, the all-gather inside the timed region, the MAX over ranks, ONE JSON
+    line from rank 0.  Not a performance number (two ranks share a GPU) and labelled as a rehearsal."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, SBR_BENCH_BACKEND="gloo")
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and c["envs_per_gpu"] == 65536 and c["envs_total"] == 131072
+    assert "REHEARSAL" in c["collective_backend"] and c["allgathers_in_timed_region"] >= 1 and c["allgather_bytes_per_rank"] == 4 * 65536
+    assert abs(d["value"] - 131072 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]      # whole-job aggregate over both ranks
+    assert "cpu_baseline" not in d                            # rank 0 at N = 1 only
+    assert "sharded over 2 GPUs" in c["workload"] and d["roofline"]["launches_timed"] == 20
