@@ -553,10 +553,11 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
     double x[SBR_NX], xa6[SBR_NXD], hist[SBR_KLA_HIST];
     SbrCtl c;
-    // x6 and the ten Kla values stay in registers: capped at 256 VGPRs for two waves per SIMD the compiler spills six
-    // loop-invariant doubles (52 B per lane), reloaded once per call outside the RK4 loops.  Parking x6, or x6 and the history,
-    // in LDS instead removes the scratch (251 VGPRs) and is 1 - 2 % SLOWER (7.57 / 7.65 against 7.50 us per call at 65536 envs,
-    // profiles/r03_ab_rollout_scratch.log); without the cap (268 VGPRs) it is 7 % slower at 131072 envs (round 2).
+    // x6 and the ten Kla values stay in registers.  With the terminal phases INSIDE the loop over the calls the kernel needed
+    // 268 VGPRs and, capped at 256 for two waves per SIMD, spilled six loop invariants to 52 B of scratch per lane; parking x6 or
+    // the history in LDS removed the spill and was 1 - 2 % slower.  Running settle / draw / idle once AFTER the loop (a finished
+    // lane skips every later call, so nothing changes in between) gives 243 VGPRs, no scratch and 2 - 3 % less time per call
+    // (profiles/r03_ab_rollout_scratch.log, r03_ab_rollout_terminal_after_loop.log).
     SbrX6Reg x6;
     SbrRewardParts rp;
     load_x(b, i0, l, x);
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     int steps, status; bool finished;
     meta_unpack(CTRL(R_META), steps, status, finished);
     double acc = 0.0;
+    bool terminal_due = false;        // the done call happened in this launch: its settle / draw / idle run once, after the loop
     for (int32_t s = 0; s < n_steps; ++s) {
         float a0, a1;
         sbr_policy_action(p, policy_seed, gid, (uint32_t)steps, a0, a1);
@@ -577,10 +579,14 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
         sbr_run_intervals<false>(p, c, x, (double)a0, (double)a1, x6);
         x6.get(xa6);
         SbrHistReg hs{hist};
-        const double r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
+        const double r = sbr_finish_step<OCI, SbrHistReg, false>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         acc += r; ret += r; status |= c.st_new;
         if (steps < SBR_MAX_STEPS) steps += 1;
-        if (dn) finished = true;
+        if (dn) { finished = true; terminal_due = !OCI && p.terminal; }
+    }
+    if (terminal_due) {               // a finished lane skipped every later call, so c, x and hist are as the done call left them
+        SbrHistReg hs{hist};
+        qw = sbr_terminal(p, c, hs, x);
     }
     store_x(b, i0, l, x);
     store_ctl(b, i0, l, c);

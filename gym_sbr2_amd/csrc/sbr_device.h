@@ -699,7 +699,10 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_N
 // xa6 is updated to the pre-settle values when the terminal phases run; qw is written only then.
 // OCI = the operating-cost reward (cfg.reward_kind 2) with its running sum(Kla) of the episode's list, ksum: a
 // compile-time variant, so that the default kernels carry none of it.
-template <bool OCI, typename H>
+// TERMINAL_INLINE = false leaves the terminal phases of the done call to the caller (the fused rollout runs them once, after its
+// loop over the calls: with them inside the loop the compiler keeps their working set alive across it - 3 % of the rollout's
+// time, profiles/r03_notes.md); the reward of a done call does not depend on them unless OCI.
+template <bool OCI, typename H, bool TERMINAL_INLINE = true>
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX],
                                double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp) {
     const double kwin = hs.commit_and_window(c);
@@ -716,7 +719,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
     dn = false;
     if (c.t >= p.T5_end) {                                               // :1122
         dn = true;
-        if (p.terminal) {
+        if ((TERMINAL_INLINE || OCI) && p.terminal) {
             sbr_take6(x, xa6);
             const double snh_eff = x[10];            // solubles pass the settler unchanged: eff_component[3] (:2642)
             qw = sbr_terminal(p, c, hs, x);

@@ -121,10 +121,6 @@ def test_secondary_kernels_carry_no_ieee_divisions(asm):
     for k in (K_RESET, K_RESET_CARRY):
         assert f64_mix(instructions(kernel_text(asm, k)))["div"] <= 4, k         # measured 0 (round 2: 19 / 20)
     assert f64_mix(instructions(kernel_text(asm, K_CYCLE_RESET)))["div"] <= 4     # measured 2 (round 2: 15)
-    # the fused rollout keeps its 52 B of spilled loop invariants on purpose (profiles/r03_ab_rollout_scratch.log): they are
-    # reloaded outside the RK4 loops, which must stay clean
-    for l in inner_loops(kernel_text(asm, K_ROLLOUT)):
-        m = f64_mix(l)
-        if m["rcp"] >= 4 and m["fma"] > 100:
-            assert m["scratch"] == 0 and m["div"] == 0
-    assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") <= 64
+    # the fused rollout: no scratch at all since its terminal phases run after the loop over the calls (round 2: 52 B per lane)
+    assert f64_mix(instructions(kernel_text(asm, K_ROLLOUT)))["scratch"] == 0
+    assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") == 0 and meta(asm, K_ROLLOUT, "vgpr_count") <= 256
