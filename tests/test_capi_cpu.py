@@ -138,3 +138,27 @@ def test_interval_row_count_thresholds_reproduce_the_ieee_quotient():
     e = golden("sbros_const_2_5")
     spans = e["iv_t_end"] - e["iv_t_start"]
     assert [rows_fast(s) for s in spans] == e["iv_n_rows"].tolist()      # the reference's own 466 intervals
+
+
+def test_header_is_plain_c_and_the_c_demo_compiles_against_it(tmp_path):
+    """The boundary is a C ABI: include/sbr_amd.h must be valid C99 on its own (no C++, no HIP types), and the plain-C caller
+    examples/c_abi_demo.c must compile and link against the library with gcc.  (It runs on the GPU box:
+    tests/test_gpu_parity.py::test_c_abi_from_plain_c_without_python_or_torch; here it must fail loudly for want of a device.)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    hdr = os.path.join(ROOT, "include", "sbr_amd.h")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("HIP runtime headers not available")
+    from gym_sbr2_amd import _capi, build as B
+    _capi.load()
+    exe, libdir = str(tmp_path / "c_abi_demo"), os.path.dirname(B.LIB)
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", libdir, "-lsbr_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert p.returncode != 0 and "no CPU path" in p.stderr
