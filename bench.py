@@ -57,11 +57,11 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the platform default; 
 ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl 72+72, action 8, obs 72, state 60, reward 4, done 1
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
-# float64 operations per RK4 substep, counted in the gfx950 ISA of the two substep loops of k_step (round 2): when no lane of
-# the wave doses carbon 159 FMA x 2 + 104 MUL + 4 ADD + 4 RCP = 430; with dosing (the loop is unrolled by two: 426 x 2 + 229 +
-# 16 + 8 per two substeps) 552.  The loops only (no PIDs, reward, observations): a LOWER bound of the work per env-step.
-# tests/test_isa_cpu.py asserts both figures against the compiler's output.
-FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 552, "filling": 590}      # filling: k_cycle's / k_reset's loop, (426 x 2 + 229 + 88 + 12) / 2
+# float64 operations per RK4 substep, counted in the gfx950 ISA of the two substep loops of k_step: when no lane of the wave
+# doses carbon 159 FMA x 2 + 104 MUL + 4 ADD + 4 RCP = 430; with dosing (round 4: the scaled-mass loop, unrolled by two:
+# 346 x 2 + 216 + 20 + 8 per two substeps) 468 (rounds 2-3, concentration form: 552).  The loops only (no PIDs, reward,
+# observations): a LOWER bound of the work per env-step.  tests/test_isa_cpu.py asserts both figures against the compiler's output.
+FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 468, "filling": 590}      # filling: k_cycle's / k_reset's loop, (426 x 2 + 229 + 88 + 12) / 2
 SUBSTEPS = 10
 # vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
 # vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles

@@ -410,12 +410,16 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
     }
 }
 
-// The first eight arguments (16 dwords) are what the first global loads need; the library is built with
+// The leading arguments (14 dwords) are what the first global loads need; the library is built with
 // -mllvm -amdgpu-kernarg-preload-count=16, so a wave starts with them in SGPRs and issues its loads without waiting for a
 // scalar load of the argument segment (two serial scalar round trips before: n for the bounds test, then the pointers).
+// `flags` carries every decision that shapes the LOAD phase (bit 0: the So[-2] / Sno[-2] rows are needed - derivative action
+// or a trace buffer), taken on the host: until round 4 that test read two fields of `p` and one of `b0`, and the s_waitcnt
+// in front of it held back EVERY global load of the wave for a scalar round trip to the argument segment.
+#define SBR_KF_NEED_M2 1u
 template <typename OutT, typename ActT, int BLK, bool OCI>
 __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
-                                                      const ActT* __restrict__ action, OutT* __restrict__ obs,
+                                                      const ActT* __restrict__ action, uint32_t flags, OutT* __restrict__ obs,
                                                       OutT* __restrict__ state, OutT* __restrict__ reward,
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
     SbrBuf b = b0;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
     // in logical order, whose rows depend on t: a second, dependent round trip)
     load_x(b, i0, l, x);
-    load_ctl_pre(b, i0, l, (p.KcD_DO != 0.0) || (p.KcD_EC != 0.0) || b.trace != nullptr, c);
+    load_ctl_pre(b, i0, l, (flags & SBR_KF_NEED_M2) != 0u, c);
     const double meta0 = CTRL(R_META);
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
@@ -915,12 +919,13 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
 template <typename OutT, typename ActT, bool OCI>
 static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                           hipStream_t st) {
+    const uint32_t flags = (e->par.KcD_DO != 0.0 || e->par.KcD_EC != 0.0 || e->buf.trace != nullptr) ? SBR_KF_NEED_M2 : 0u;
     if (e->n <= SBR_SMALL_BATCH)
         hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
-                           e->buf.n, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
+                           e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
         hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
-                           e->buf.ctrl, e->buf.n, (const ActT*)action, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par,
+                           e->buf.ctrl, e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par,
                            e->buf);
 }
 template <typename OutT, typename ActT>
@@ -1009,6 +1014,10 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
         !(c.Koh > 0 && c.Koh < 1e300))
         bad = "muH, muA, kh, eta_g, Koh, bH and Ya must be positive";
     if (c.substeps > (1 << 20)) bad = "substeps out of range";
+    // the dosing integrator expands 1/s, s = V/V0, to third order in s - 1 <= EC_max t_delta / V (sbr_rk4_dose): 7e-7 with
+    // the reference's EC_max; refuse configurations in which the truncation (s - 1)^4 would reach 1e-16
+    if (!(c.IV > 0) || !(c.WV > 0) || !(c.EC_max * c.t_delta <= 1e-4 * (c.IV < c.WV ? c.IV : c.WV)))
+        bad = "EC_max * t_delta must be below 1e-4 of the reactor volume (IV, WV > 0)";
     for (int k = 0; k < 8; ++k) if (!(c.t_ratio[k] > 0)) bad = "t_ratio entries must be positive";
     if (!bad.empty()) { delete e; return fail(nullptr, SBR_ERR_INVALID, "sbr_create: " + bad); }
     derive_params(c, e->par);

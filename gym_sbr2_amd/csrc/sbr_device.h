@@ -133,15 +133,22 @@ struct SbrRho { double rho1, rho2, rho3, rho6, s45b; };        // s45b = (rho4 +
 // wave-mate doses carbon, so an env's arithmetic does not depend on which envs share its wavefront.
 // Parity is to tolerance, not bitwise (RHS known answers within 2e-15 relative).
 // Returns k[] = d/dt of the nine components, EXCEPT k[A_SNO] = (d Sno/dt)/nu9_3.
-SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, double kla_sat, double (&k)[SBR_NA],
+//
+// The seven constants in SbrMonod are the ones that are NOT homogeneous of degree one in the concentrations.  ASM1's rates
+// are: with a[] = s c (the scaled-mass variables of the dosing integrator, sbr_rk4_dose) and these seven scaled by s = V/V0
+// (f3a and ka by 1/s), the function returns s r(c) - the same 49 + 1 instructions.  Every other caller passes the model's
+// own constants (sbr_monod: wave-uniform, they stay in SGPRs).
+struct SbrMonod { double f1b, f2b, f3a, f4b, Koa, kla_sat, ka; };
+SBR_DEV SbrMonod sbr_monod(const SbrPar& p, double kla_sat) { return SbrMonod{p.f1b, p.f2b, p.f3a, p.f4b, p.Koa, kla_sat, p.ka}; }
+SBR_DEV void sbr_rates(const SbrPar& p, const SbrMonod& m, const double (&a)[SBR_NA], double kla, double (&k)[SBR_NA],
                        SbrRho& o) {
     const double ss = a[A_SS], xs = a[A_XS], xbh = a[A_XBH], xba = a[A_XBA], so = a[A_SO], sno = a[A_SNO], snh = a[A_SNH],
                  snd = a[A_SND], xnd = a[A_XND];
-    const double d1 = __builtin_fma(ss, p.f1a, p.f1b);        // (Ks + Ss) kh/muH
-    const double d2 = __builtin_fma(so, p.f2a, p.f2b);        // (Koh + So)/kh
-    const double d3 = __builtin_fma(sno, p.f3a, p.f3b);       // (Kno + Sno)/(eta_g Koh)
-    const double d4 = __builtin_fma(snh, p.f4a, p.f4b);       // (Knh + Snh)/muA
-    const double d5 = p.Koa + so;
+    const double d1 = __builtin_fma(ss, p.f1a, m.f1b);        // (Ks + Ss) kh/muH
+    const double d2 = __builtin_fma(so, p.f2a, m.f2b);        // (Koh + So)/kh
+    const double d3 = __builtin_fma(sno, m.f3a, p.f3b);       // (Kno + Sno)/(eta_g Koh)
+    const double d4 = __builtin_fma(snh, p.f4a, m.f4b);       // (Knh + Snh)/muA
+    const double d5 = m.Koa + so;
     const double d6 = __builtin_fma(p.Kx, xbh, xs);
     // one reciprocal of d1 d2 d3 d6 (d4 d5), then exactly the four quotients the rates use: 5 + 7 multiplications
     const double A = d1 * d2, B = d4 * d5, Cc = d3 * d6, AC = A * Cc;
@@ -165,12 +172,12 @@ SBR_DEV void sbr_rates(const SbrPar& p, const double (&a)[SBR_NA], double kla, d
     k[A_XS] = __builtin_fma(p.n4_45b, s45b, -rho7);
     k[A_XBH] = __builtin_fma(-p.bH, xbh, s12);
     k[A_XBA] = __builtin_fma(-p.bA, xba, rho3);
-    k[A_SO] = __builtin_fma(p.n8_1, rho1, __builtin_fma(p.n8_3, rho3, __builtin_fma(-kla, so, kla_sat)));   // + kla (So_sat - So)
+    k[A_SO] = __builtin_fma(p.n8_1, rho1, __builtin_fma(p.n8_3, rho3, __builtin_fma(-kla, so, m.kla_sat)));   // + kla (So_sat - So)
     k[A_SNO] = __builtin_fma(p.n9_23, rho2, rho3);             // (nu9_2 rho2 + nu9_3 rho3)/nu9_3
-    k[A_SNH] = __builtin_fma(p.n10_12, s12, __builtin_fma(p.n10_3, rho3, p.ka * z));
-    k[A_SND] = __builtin_fma(-p.ka, z, rho8);
+    k[A_SNH] = __builtin_fma(p.n10_12, s12, __builtin_fma(p.n10_3, rho3, m.ka * z));
+    k[A_SND] = __builtin_fma(-m.ka, z, rho8);
     k[A_XND] = __builtin_fma(p.n12_45b, s45b, -rho8);
-    o.rho1 = rho1; o.rho2 = rho2; o.rho3 = rho3; o.rho6 = p.ka * z; o.s45b = s45b;
+    o.rho1 = rho1; o.rho2 = rho2; o.rho3 = rho3; o.rho6 = m.ka * z; o.s45b = s45b;
 }
 
 // All 14 derivatives of one state, for the known-answer kernel only.  KIND 0: reaction_dxdt :1658-1787 (dosing ec,
@@ -181,7 +188,7 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
     double a[SBR_NA], k[SBR_NA], r[SBR_NX];
     SbrRho o;
     sbr_gather(x, a);
-    sbr_rates(p, a, kla, kla * p.So_sat, k, o);
+    sbr_rates(p, sbr_monod(p, kla * p.So_sat), a, kla, k, o);
     r[0] = 0.0; r[1] = 0.0; r[3] = 0.0;
     k[A_SNO] = k[A_SNO] * p.n9_3;
     sbr_scatter(k, r);
@@ -205,29 +212,126 @@ SBR_DEV void sbr_rhs(const SbrPar& p, const double (&x)[SBR_NX], double kla, dou
 
 // Classical RK4, n equal substeps of length h; autonomous inside a call (Kla and the inflow held).
 //   FLOW 0: closed reactor - reaction intervals in which this wave doses no carbon, idle phase (idle_dxdt :2424-2552)
-//   FLOW 1: carbon dosing - inflow Q = ec of concentration EC_conc in Ss, nothing else (reaction_dxdt :1757-1785)
+//   FLOW 1: carbon dosing - inflow Q = ec of concentration EC_conc in Ss, nothing else (reaction_dxdt :1757-1785):
+//           integrated in scaled-mass variables, sbr_rk4_dose below
 //   FLOW 2: filling - inflow Q = ld[0] of composition ld[1..13] (filling_dxdt :1555-1581)
 // Only the nine feedback components are carried through the stages (x, the running combination and one stage vector:
 // 3 x 9 doubles live).  The rest of the state has closed forms that RK4 reproduces to (Q h/V)^5 ~ 1e-38, i.e. exactly:
-//   V' = Q                      =>  V advances by h Q per substep; 1/V at the stage times is tracked by one Newton step
-//                                   (dosing moves V by 3e-8 of itself per substep) or taken afresh (filling),
+//   V' = Q                      =>  V advances by h Q per substep; 1/V at the stage times is taken afresh (filling),
 //   c' = (Q/V)(c_in - c)        =>  c(t1) = c0 + g (c_in - c0), g = (V1 - V0)/V1, for Si and Xi (no reaction), and for
 //   u = Salk - (Snh - Sno)/14       the charge balance u: the alkalinity row of the stoichiometry is (row Snh - row Sno)/14
 //                                   for every process (nu13_k = (nu10_k - nu9_k)/14 term by term, :1689-1725), so u only
 //                                   dilutes,
 //   Xp' = nu7 (rho4 + rho5) + (Q/V)(c_in - Xp): nothing depends on Xp, so without inflow it needs no stage value, only the
 //                                   weighted sum of rho4 + rho5 (one FMA per stage).
-// With Q == 0 every flow term is an exact no-op (q = 0, g = 0: each is a separate FMA whose product is then +-0), so a
-// lane that doses nothing computes bit for bit the same in the FLOW 1 code as in the FLOW 0 code: results do not depend
-// on the wave-mates.
+
+// Carbon dosing (FLOW 1) in SCALED-MASS variables w_i = c_i V/V0 = c_i s, V0 = the volume at the start of the interval,
+// s(t) = V(t)/V0 = 1 + Q t/V0 (round 4; the RK4 layers of the CPU oracle under oracle/ - test infrastructure, never linked
+// here - integrate the same system: `rk4_reaction_w` in its C and NumPy files).  In w the dilution terms -(Q/V) c_i of reaction_dxdt (:1757-1785)
+// disappear IDENTICALLY:
+//     w_i' = s r_i(w/s) + (Q/V0) c_in,i            c_in = EC_conc for Ss, 0 for everything else,
+// and because every ASM1 rate is homogeneous of degree one in (concentrations, half-saturation constants) - except
+// ammonification rho6 = ka Snd Xbh, which is of degree two - s r(w/s) is sbr_rates evaluated ON w with the additive
+// constants of the Monod denominators and the saturation term of the aeration scaled by s, and f3a (it carries 1/Koh: the
+// Koh in the numerator of the anoxic switch) and ka scaled by 1/s (SbrMonod).  What the concentration form paid per STAGE -
+// nine dilution FMAs, the source term, q = Q/V and its 1/V tracking, the inflow terms of Xp: 68 of 343 instructions per
+// substep - becomes 11 instructions per distinct STAGE TIME (two per substep: t + h/2, and t + h which is the next
+// substep's t) and two additions for the constant source of Ss (folded into the stage bases: y_j = (a + c_j h src) +
+// c_j h k): 299 instructions per substep.
+//   * 1/s = 1 - e + e^2 - e^3 with e = s - 1 = Q t/V0: e <= 7e-7 over an interval with the reference's EC_max (sbr_create
+//     rejects configurations with EC_max t_delta > 1e-4 IV), so the truncation e^4 is below 1e-16 relative.
+//   * w = c at the start of every interval (s = 1), and c = w / s_end at its end: one multiplication per component; Si,
+//     Xi and the charge balance u = Salk - (Snh - Sno)/14 have w' = 0, Xp has no source: they need no stage values.
+//   * A lane with Q == 0 has e = 0, s = 1/s = 1, every scaled constant equal to the model's own (fma(K, 0, K) = K, K*1 = K)
+//     and source 0 (a + 0 = a): it executes, operation for operation, the arithmetic of the FLOW 0 loop on the same
+//     numbers - bit for bit the same result whether or not a wave-mate doses (the ballot only selects the code path).
+//   * RK4 on w is not RK4 on c: the two discretisations differ by ~(Q h/V) x the local truncation error, 1e-14 relative
+//     per substep.  The oracle integrates w as well, so device-vs-oracle stays a rounding-level comparison; both stay
+//     pinned to the reference's LSODA trajectories by the same gates as before (tests/test_oracle_golden.py).
+struct SbrScaled { SbrMonod m; double rs; };
+SBR_DEV SbrScaled sbr_scale_consts(const SbrPar& p, double kla_sat, double e) {
+    SbrScaled o;
+    const double r1 = __builtin_fma(-e, 1.0, 1.0);             // 1 - e
+    const double r2 = __builtin_fma(-e, r1, 1.0);              // 1 - e + e^2
+    o.rs = __builtin_fma(-e, r2, 1.0);                         // 1 - e + e^2 - e^3 = 1/(1 + e) - e^4/(1 + e)
+    o.m.f1b = __builtin_fma(p.f1b, e, p.f1b); o.m.f2b = __builtin_fma(p.f2b, e, p.f2b); o.m.f4b = __builtin_fma(p.f4b, e, p.f4b);
+    o.m.Koa = __builtin_fma(p.Koa, e, p.Koa); o.m.kla_sat = __builtin_fma(kla_sat, e, kla_sat);
+    o.m.f3a = p.f3a * o.rs; o.m.ka = p.ka * o.rs;
+    return o;
+}
+SBR_DEV void sbr_rk4_dose(const SbrPar& p, double (&x)[SBR_NX], double h, int n, double kla, double Q) {
+    const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
+    const double g1 = h * p.n9_3, g2 = h2 * p.n9_3, g6 = h6 * p.n9_3, g3 = h3 * p.n9_3;      // sbr_rates returns Sno's derivative over nu9_3
+    const double p6 = h6 * p.n7_45b, p3 = h3 * p.n7_45b;                                      // Xp' = nu7 bH s45b, no source
+    const double kla_sat = kla * p.So_sat;
+    const double v0 = x[0];
+    const double dl = (h * Q) * sbr_rcp(v0), dl2 = 0.5 * dl;   // growth of s per substep / per half substep
+    const double src1 = dl * p.EC_conc, src2 = 0.5 * src1;     // h (Q/V0) EC_conc and half of it: the source of Ss over a (half) substep
+    double a[SBR_NA], xp = x[7], e = 0.0;
+    sbr_gather(x, a);
+    const double n0 = x[10] - x[9];                            // Snh - Sno at the start (charge balance)
+    SbrScaled c0 = sbr_scale_consts(p, kla_sat, 0.0);          // the model's own constants, exactly
+#pragma unroll 2
+    for (int s = 0; s < n; ++s) {
+        double k[SBR_NA], y[SBR_NA], acc[SBR_NA], acc7;
+        SbrRho o;
+        const double ss1 = a[A_SS] + src1, ss2 = a[A_SS] + src2;        // stage bases of Ss with the source folded in
+        // stage 1 at (t, s)
+        sbr_rates(p, c0.m, a, kla, k, o);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g6 : h6, k[i], i == A_SS ? ss1 : a[i]);
+            y[i] = __builtin_fma(i == A_SNO ? g2 : h2, k[i], i == A_SS ? ss2 : a[i]);
+        }
+        acc7 = __builtin_fma(p6, o.s45b, xp);
+        // stages 2 and 3 at (t + h/2, s + dl/2)
+        const SbrScaled cm = sbr_scale_consts(p, kla_sat, e + dl2);
+        sbr_rates(p, cm.m, y, kla, k, o);
+        acc7 = __builtin_fma(p3, o.s45b, acc7);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g3 : h3, k[i], acc[i]);
+            y[i] = __builtin_fma(i == A_SNO ? g2 : h2, k[i], i == A_SS ? ss2 : a[i]);
+        }
+        sbr_rates(p, cm.m, y, kla, k, o);
+        acc7 = __builtin_fma(p3, o.s45b, acc7);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            acc[i] = __builtin_fma(i == A_SNO ? g3 : h3, k[i], acc[i]);
+            y[i] = __builtin_fma(i == A_SNO ? g1 : h, k[i], i == A_SS ? ss1 : a[i]);
+        }
+        // stage 4 at (t + h, s + dl): its constants are the next substep's stage-1 constants
+        e = e + dl;
+        c0 = sbr_scale_consts(p, kla_sat, e);
+        sbr_rates(p, c0.m, y, kla, k, o);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(i == A_SNO ? g6 : h6, k[i], acc[i]);
+        xp = __builtin_fma(p6, o.s45b, acc7);
+    }
+    // back to concentrations: c = w / s_end
+    const double rs = c0.rs, c14 = 1.0 / 14.0;
+#pragma unroll
+    for (int i = 0; i < SBR_NA; ++i) a[i] = a[i] * rs;
+    sbr_scatter(a, x);
+    x[7] = xp * rs;
+    x[0] = __builtin_fma(v0, e, v0);                           // V0 s_end
+    x[1] = x[1] * rs; x[3] = x[3] * rs;                        // Si, Xi: w' = 0
+    const double u = __builtin_fma(-n0, c14, x[13]) * rs;      // charge balance: w' = 0
+    x[13] = __builtin_fma(x[10] - x[9], c14, u);
+}
+
 template <int FLOW>
 SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, double kla, double Q,
                      const double (&ld)[SBR_NX]) {
+    if constexpr (FLOW == 1) {
+        sbr_rk4_dose(p, x, h, n, kla, Q);
+        return;
+    }
     const double h2 = 0.5 * h, h6 = h * (1.0 / 6.0), h3 = h * (1.0 / 3.0);
     // sbr_rates returns Sno's derivative over nu9_3 and decay over bH: their step constants carry the factors
     const double g1 = h * p.n9_3, g2 = h2 * p.n9_3, g6 = h6 * p.n9_3, g3 = h3 * p.n9_3;
     const double p2 = h2 * p.n7_45b, p1 = h * p.n7_45b, p6 = h6 * p.n7_45b, p3 = h3 * p.n7_45b;     // Xp' = nu7 bH s45b
-    const double kla_sat = kla * p.So_sat;
+    const SbrMonod m = sbr_monod(p, kla * p.So_sat);
     double a[SBR_NA], xp = x[7];
     sbr_gather(x, a);
     const double v0 = x[0], n0 = x[10] - x[9];                 // V and Snh - Sno at the start
@@ -240,11 +344,7 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
         SbrRho o;
         // what the inflow adds to the stage derivative of w[] (Sno's is carried over nu9_3: qn = q/nu9_3)
         auto flow = [&](const double (&w)[SBR_NA]) {
-            if (FLOW == 1) {
-#pragma unroll
-                for (int i = 0; i < SBR_NA; ++i)
-                    k[i] = __builtin_fma(i == A_SNO ? qn : q, i == A_SS ? (p.EC_conc - w[i]) : -w[i], k[i]);
-            } else if (FLOW == 2) {
+            if (FLOW == 2) {
                 k[A_SS] = __builtin_fma(q, ld[2] - w[A_SS], k[A_SS]); k[A_XS] = __builtin_fma(q, ld[4] - w[A_XS], k[A_XS]);
                 k[A_XBH] = __builtin_fma(q, ld[5] - w[A_XBH], k[A_XBH]); k[A_XBA] = __builtin_fma(q, ld[6] - w[A_XBA], k[A_XBA]);
                 k[A_SO] = __builtin_fma(q, ld[8] - w[A_SO], k[A_SO]); k[A_SNO] = __builtin_fma(qn, ld[9] - w[A_SNO], k[A_SNO]);
@@ -252,10 +352,10 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
                 k[A_XND] = __builtin_fma(q, ld[12] - w[A_XND], k[A_XND]);
             }
         };
-        // Xp: acc7 += w_s (nu7 (rho4+rho5) + q (c_in - w7)), as two FMAs so that q == 0 is an exact no-op
-        auto xp_in = [&](double w7) { return FLOW == 2 ? ld[7] - w7 : -w7; };
+        // Xp: acc7 += w_s (nu7 (rho4+rho5) + q (c_in - w7)), as two FMAs
+        auto xp_in = [&](double w7) { return ld[7] - w7; };
         // stage 1 at (t, V)
-        sbr_rates(p, a, kla, kla_sat, k, o);
+        sbr_rates(p, m, a, kla, k, o);
         if (FLOW) { q = Q * rv; qn = q * p.inv_n9_3; flow(a); }
 #pragma unroll
         for (int i = 0; i < SBR_NA; ++i) {
@@ -266,10 +366,10 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
         // stages 2 and 3 at (t + h/2, V + h/2 Q)
         if (FLOW) {
             const double vm = __builtin_fma(h2, Q, v);
-            rv = FLOW == 1 ? sbr_rcp_refine(vm, rv) : sbr_rcp(vm);
+            rv = sbr_rcp(vm);
             q = Q * rv; qn = q * p.inv_n9_3;
         }
-        sbr_rates(p, y, kla, kla_sat, k, o);
+        sbr_rates(p, m, y, kla, k, o);
         if (FLOW) flow(y);
         acc7 = __builtin_fma(p3, o.s45b, acc7);
         if (FLOW) { acc7 = __builtin_fma(h3 * q, xp_in(y7), acc7); y7 = __builtin_fma(h2 * q, xp_in(y7), __builtin_fma(p2, o.s45b, xp)); }
@@ -277,7 +377,7 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
         for (int i = 0; i < SBR_NA; ++i) {
             acc[i] = __builtin_fma(i == A_SNO ? g3 : h3, k[i], acc[i]); y[i] = __builtin_fma(i == A_SNO ? g2 : h2, k[i], a[i]);
         }
-        sbr_rates(p, y, kla, kla_sat, k, o);
+        sbr_rates(p, m, y, kla, k, o);
         if (FLOW) flow(y);
         acc7 = __builtin_fma(p3, o.s45b, acc7);
         if (FLOW) { acc7 = __builtin_fma(h3 * q, xp_in(y7), acc7); y7 = __builtin_fma(h * q, xp_in(y7), __builtin_fma(p1, o.s45b, xp)); }
@@ -288,10 +388,10 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
         // stage 4 at (t + h, V + h Q)
         if (FLOW) {
             v = __builtin_fma(h, Q, v);
-            rv = FLOW == 1 ? sbr_rcp_refine(v, rv) : sbr_rcp(v);
+            rv = sbr_rcp(v);
             q = Q * rv; qn = q * p.inv_n9_3;
         }
-        sbr_rates(p, y, kla, kla_sat, k, o);
+        sbr_rates(p, m, y, kla, k, o);
         if (FLOW) flow(y);
 #pragma unroll
         for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(i == A_SNO ? g6 : h6, k[i], acc[i]);
@@ -304,12 +404,11 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
     const double c14 = 1.0 / 14.0;
     double u = __builtin_fma(-n0, c14, x[13]);                 // Salk - (Snh - Sno)/14 at the start
     if (FLOW) {
-        const double g = (v - v0) * rv;                        // share of the final volume that flowed in; 0 if Q == 0
-        const double si_in = FLOW == 2 ? ld[1] : 0.0, xi_in = FLOW == 2 ? ld[3] : 0.0;
-        const double u_in = FLOW == 2 ? __builtin_fma(-(ld[10] - ld[9]), c14, ld[13]) : 0.0;
+        const double g = (v - v0) * rv;                        // share of the final volume that flowed in
+        const double u_in = __builtin_fma(-(ld[10] - ld[9]), c14, ld[13]);
         x[0] = v;
-        x[1] = __builtin_fma(g, si_in - x[1], x[1]);
-        x[3] = __builtin_fma(g, xi_in - x[3], x[3]);
+        x[1] = __builtin_fma(g, ld[1] - x[1], x[1]);
+        x[3] = __builtin_fma(g, ld[3] - x[3], x[3]);
         u = __builtin_fma(g, u_in - u, u);
     }
     x[13] = __builtin_fma(x[10] - x[9], c14, u);

@@ -157,10 +157,13 @@ void sbro_eval_rhs(const sbro_params* p, int kind, int64_t n, const double* x, c
     }
 }
 
+static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, double kla, double ec);
+
 /* classical RK4, n equal substeps over [0, span]; the systems are autonomous inside a span.
  * kind 0: reaction(kla, ec)  1: fill(kla, loading)  2: idle(kla) */
 static void rk4_span(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,
                      const double* loading) {
+    if (kind == 0 && ec != 0.0) { rk4_reaction_w(p, x, span, n, kla, ec); return; }
     const double h = span / n;
     double k1[NX], k2[NX], k3[NX], k4[NX], y[NX];
     for (int s = 0; s < n; ++s) {
@@ -180,6 +183,47 @@ static void rk4_span(const sbro_params* p, int kind, double* x, double span, int
         for (int i = 0; i < NX; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
 #undef F
     }
+}
+
+/* A reaction interval that doses carbon (ec != 0), integrated in SCALED-MASS variables (round 4; the HIP kernels' dosing
+ * loop sbr_rk4_dose integrates the same system, and so does oracle/sbr_ref.py rk4_reaction_w, bit for bit like this):
+ *     w_i = c_i V/V0 = c_i s,   V0 = the volume at the start of the interval,   s = V/V0.
+ * reaction_dxdt (:1658-1787) is  V' = ec,  c_i' = r_i(c) + (ec/V)(c_in,i - c_i)  with c_in = EC_conc for Ss and 0 otherwise;
+ * substituting c = w/s gives the SAME differential equations without the dilution terms,
+ *     V' = ec,   w_i' = s r_i(w/s) + (ec/V0) c_in,i ,
+ * an autonomous system in (V, w) on which classical RK4 is run as before; at the end of the interval c = w/s.  It is a
+ * restatement of the reference's right-hand side in other variables, not another model: r is the reference's conversion()
+ * evaluated on c = w/s.  RK4 on w and RK4 on c are both fourth-order discretisations of that system and differ by
+ * ~(ec h/V) x the local truncation error (1e-14 relative per substep); both stay inside the same gates of the reference's
+ * LSODA trajectories (tests/test_oracle_golden.py).  With ec == 0 the two coincide operation for operation (s = 1), so
+ * rk4_span keeps the plain form there. */
+static void rhs_reaction_w(const sbro_params* p, const double* y, double v0, double kla, double ec, double* d) {
+    double c[NX], r[NX];
+    const double s = y[0] / v0;
+    c[0] = y[0];
+    for (int i = 1; i < NX; ++i) c[i] = y[i] / s;
+    conversion(p, c, kla, r);
+    const double q0 = ec / v0;
+    d[0] = 0 + ec;
+    for (int i = 1; i < NX; ++i) d[i] = s * r[i] + q0 * (i == 2 ? p->EC_conc : 0.0);
+}
+
+static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, double kla, double ec) {
+    const double h = span / n;
+    const double v0 = x[0];
+    double k1[NX], k2[NX], k3[NX], k4[NX], y[NX];
+    for (int s = 0; s < n; ++s) {            /* x = (V, w); w = c at the start of the interval (s = 1) */
+        rhs_reaction_w(p, x, v0, kla, ec, k1);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (0.5 * h) * k1[i];
+        rhs_reaction_w(p, y, v0, kla, ec, k2);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (0.5 * h) * k2[i];
+        rhs_reaction_w(p, y, v0, kla, ec, k3);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + h * k3[i];
+        rhs_reaction_w(p, y, v0, kla, ec, k4);
+        for (int i = 0; i < NX; ++i) x[i] = x[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    const double s_end = x[0] / v0;
+    for (int i = 1; i < NX; ++i) x[i] = x[i] / s_end;
 }
 
 void sbro_rk4(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,

@@ -136,6 +136,40 @@ def rk4(f, x, t0, t1, n, args):
     return x
 
 
+def rhs_reaction_w(y, v0, kla, ec):
+    """reaction_dxdt (gym_SBR_oneshot.py:1658-1787) in scaled-mass variables y = (V, w), w_i = c_i V/V0: substituting
+    c = w/s, s = V/V0, into V' = ec, c_i' = r_i(c) + (ec/V)(c_in,i - c_i) removes the dilution terms identically:
+    w_i' = s r_i(w/s) + (ec/V0) c_in,i with c_in = EC_conc for Ss, 0 otherwise.  Same operations, in the same order, as
+    rhs_reaction_w of oracle/sbr_oracle.c."""
+    s = y[0] / v0
+    c = [y[0]] + [y[i] / s for i in range(1, 14)]
+    r = conversion(c, kla)
+    q0 = ec / v0
+    d = np.zeros(14)
+    d[0] = 0 + ec
+    for i in range(1, 14):
+        d[i] = s * r[i] + q0 * (P.EC_CONC if i == 2 else 0.0)
+    return d
+
+
+def rk4_reaction_w(x, t0, t1, n, kla, ec):
+    """A carbon-dosing reaction interval (ec != 0) by classical RK4 on the scaled-mass system (round 4): what the HIP
+    kernels' dosing loop integrates (sbr_device.h, sbr_rk4_dose) and, bit for bit, what oracle/sbr_oracle.c rk4_reaction_w
+    does.  w = c at the start of the interval (s = 1), c = w/s at its end."""
+    h = (t1 - t0) / n
+    x = np.array(x, dtype=np.float64)
+    v0 = x[0]
+    for _ in range(n):
+        k1 = rhs_reaction_w(x, v0, kla, ec)
+        k2 = rhs_reaction_w(x + (0.5 * h) * k1, v0, kla, ec)
+        k3 = rhs_reaction_w(x + (0.5 * h) * k2, v0, kla, ec)
+        k4 = rhs_reaction_w(x + h * k3, v0, kla, ec)
+        x = x + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+    s_end = x[0] / v0
+    x[1:] = x[1:] / s_end
+    return x
+
+
 def influent_mix(means, stds, rnd):
     """buffer_tank3.py:68-107 for one scenario: series = mean + std*rnd (one rnd vector shared by
     all series), flow-weighted means; returns [0.66, Si..Salk].  means/stds: [14,48], last row = q."""
@@ -179,6 +213,8 @@ class SbrOsRef:
             grid = np.linspace(t0, t1, n_rows)
             rows = odeint(f, x, grid, args=args)
             return rows[-1].copy(), rows
+        if f is rhs_reaction and args[1] != 0:          # a dosing interval: RK4 on the scaled-mass system (rk4_reaction_w)
+            return rk4_reaction_w(x, t0, t1, n_sub, *args), None
         return rk4(f, x, t0, t1, n_sub, args), None
 
     # ------------------------------------------------------------------ reset (:168-438)

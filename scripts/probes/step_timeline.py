@@ -25,6 +25,8 @@ for N in sizes:
     env = SbrOSVec(N)
     scen = (torch.arange(N, device="cuda") % 8).to(torch.int32)
     a = torch.rand(N, 2, device="cuda") * torch.tensor([8.0, 15.0], device="cuda")
+    if os.environ.get("SBR_TL_POLICY") == "dose":      # NO3 set-point 0: every lane doses carbon in the anoxic phases
+        a[:, 1] = 0.0
     waves = (N + 63) // 64
     buf = torch.zeros(waves, 8, dtype=torch.int64, device="cuda")
     for phase_calls, label in ((20, "anoxic (dosing code path)"), (120, "aerobic (no dosing)")):

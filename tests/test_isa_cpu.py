@@ -86,6 +86,10 @@ def test_rk4_substep_loops_have_the_quoted_instruction_mix(asm):
     per_substep = sorted({(m["fma"] * 2 + m["mul"] + m["add"] + m["rcp"]) // 2 for m in rk4})
     # bench.py's roofline.fp64_valu counts exactly these loops (FMA = 2 FLOP)
     assert per_substep[0] == bench.FP64_FLOP_PER_SUBSTEP["plain"] and per_substep[-1] == bench.FP64_FLOP_PER_SUBSTEP["dosing"], per_substep
+    # the dosing loop in scaled-mass variables - at most 310 instructions per substep (measured 296.5;
+    # the concentration form of rounds 2-3 had 343.5), the closed loop unchanged at 275
+    per_substep_instr = sorted(len(l) / 2.0 for l in loops if f64_mix(l)["rcp"] == 8 and f64_mix(l)["fma"] > 250)
+    assert per_substep_instr[-1] <= 310 and per_substep_instr[0] <= 276, per_substep_instr
     for l in loops:
         m = f64_mix(l)
         if m["rcp"] == 8 and m["fma"] > 250:
