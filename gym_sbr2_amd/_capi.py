@@ -11,9 +11,11 @@ from . import build as _build
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
-NTRACE = 31          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
+ABI_VERSION = 4      # SBR_ABI_VERSION of include/sbr_amd.h; load() refuses a library that reports another
+NTRACE = 34          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
 (TR_T, TR_X0, TR_KLA, TR_EC, TR_REWARD, TR_DONE, TR_U_DO, TR_U_EC, TR_E_EC, TR_IE_EC, TR_DCV_EC, TR_R_EQI, TR_R_OCI, TR_R_AE,
- TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST) = (0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30)
+ TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST, TR_E_EC_FIRST, TR_IE_EC_FIRST, TR_DCV_EC_FIRST) = (
+     0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33)
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
@@ -46,6 +48,7 @@ class SbrError(RuntimeError):
 _VP, _I64, _U64, _I32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32
 SYMBOLS = {
     "sbr_version": (C.c_char_p, []),
+    "sbr_abi_version": (C.c_int, []),
     "sbr_default_config": (C.c_int, [C.POINTER(SbrConfig)]),
     "sbr_device_count": (C.c_int, []),
     "sbr_rows_thresholds": (C.c_int, [C.POINTER(SbrConfig), C.POINTER(C.c_double)]),
@@ -56,7 +59,7 @@ SYMBOLS = {
     "sbr_set_influent_tables": (C.c_int, [_VP, _VP, _VP]),
     "sbr_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_reset_carry": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "sbr_set_trace": (C.c_int, [_VP, _VP, _I64, _I64]),
+    "sbr_set_trace": (C.c_int, [_VP, _VP, _I64, _I64, _I32]),
     "sbr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_cycle_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _I32, _VP, _VP]),
     "sbr_cycle_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
@@ -112,6 +115,9 @@ def load(build_if_missing=True):
                 raise
             continue                   # an A/B variant built from an older source tree may lack newer entry points
         fn.restype, fn.argtypes = res, args
+    if path == _build.LIB and lib.sbr_abi_version() != ABI_VERSION:
+        raise SbrError("libsbr_amd.so reports ABI version %d, this binding was written for %d: rebuild the library "
+                       "(python -c 'import __graft_entry__ as g; g.build()')" % (lib.sbr_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

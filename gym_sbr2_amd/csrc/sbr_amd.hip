@@ -142,7 +142,7 @@ SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2,
     c.so_m2 = need_m2 ? CTRL(R_SO_M2) : c.so_m1;
     c.sno_m2 = need_m2 ? CTRL(R_SNO_M2) : c.sno_m1;
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
-    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9; c.e_ec = 0.0; c.dcv_ec = 0.0;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
 }
 // rows every step rewrites (the ring slot(s), return and meta are written by the caller)
 SBR_DEV void store_ctl(const SbrBuf& b, int64_t i0, uint32_t l, const SbrCtl& c) {
@@ -410,6 +410,44 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
     }
 }
 
+// The model constants (SbrPar, 1.2 KB) travel in the kernel-argument segment and the compiler fetches them with scalar
+// loads where it needs them - in pieces, because ~60 doubles do not fit the scalar register file at once.  The argument
+// segment of a launch is a fresh buffer in device memory that no cache has seen: the first touch of each of its 64-byte lines
+// is a miss in the scalar cache that goes out to L2 / memory, and every such piece sits behind its own s_waitcnt ON the
+// wave's critical path (PMC, round 4: SQ_WAIT_ANY is what grew when an unrelated code change added two late scalar loads,
+// +0.3 us per launch).  So every line of the segment is touched ONCE, all at the same time, right after the wave's global
+// loads have been issued: the misses overlap each other and the ~2 us of global-load latency, and every later scalar load
+// of a constant hits the scalar cache.  The loads target one scratch SGPR whose value is never used; the s_waitcnt inside
+// the statement makes sure none of them is still in flight when the compiler reuses that register.
+#ifndef SBR_WARM_MODE
+#define SBR_WARM_MODE 2        // 0 off, 1 one statement after the global loads, 2 issued at wave start and awaited after the global loads (measured best: profiles/r04_notes.md)
+#endif
+#ifndef SBR_PIN_LOADS
+#define SBR_PIN_LOADS 0
+#endif
+#define SBR_WARM_LINES                                                                                                            \
+        "s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n s_load_dword %0, %1, 0x100\n"        \
+        "s_load_dword %0, %1, 0x140\n s_load_dword %0, %1, 0x180\n s_load_dword %0, %1, 0x1c0\n s_load_dword %0, %1, 0x200\n"     \
+        "s_load_dword %0, %1, 0x240\n s_load_dword %0, %1, 0x280\n s_load_dword %0, %1, 0x2c0\n s_load_dword %0, %1, 0x300\n"     \
+        "s_load_dword %0, %1, 0x340\n s_load_dword %0, %1, 0x380\n s_load_dword %0, %1, 0x3c0\n s_load_dword %0, %1, 0x400\n"     \
+        "s_load_dword %0, %1, 0x440\n s_load_dword %0, %1, 0x480\n s_load_dword %0, %1, 0x4c0\n s_load_dword %0, %1, 0x500\n"     \
+        "s_load_dword %0, %1, 0x538\n"
+SBR_DEV void sbr_warm_kernarg() {
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t t;
+    asm volatile(SBR_WARM_LINES "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(kp) : "memory");
+    (void)t;
+}
+// the same in two halves: the scratch register stays allocated (an in/out operand of the second statement) until the loads
+// have landed, so the compiler cannot hand it to anything else while they are in flight
+SBR_DEV uint32_t sbr_warm_kernarg_issue() {
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t t;
+    asm volatile(SBR_WARM_LINES : "=&s"(t) : "s"(kp) : "memory");
+    return t;
+}
+SBR_DEV void sbr_warm_kernarg_wait(uint32_t t) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t) : : "memory"); }
+
 // The leading arguments (14 dwords) are what the first global loads need; the library is built with
 // -mllvm -amdgpu-kernarg-preload-count=16, so a wave starts with them in SGPRs and issues its loads without waiting for a
 // scalar load of the argument segment (two serial scalar round trips before: n for the bounds test, then the pointers).
@@ -417,6 +455,27 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
 // or a trace buffer), taken on the host: until round 4 that test read two fields of `p` and one of `b0`, and the s_waitcnt
 // in front of it held back EVERY global load of the wave for a scalar round trip to the argument segment.
 #define SBR_KF_NEED_M2 1u
+// trajectory export: the NO3-PID's e / ie / dcv of every interval go straight to the call's trace record while the PID runs
+// (slot _FIRST for the first interval of the call, the plain slots for the last one run), so that nothing has to be carried
+// across the integration for it.  Off (b.trace == NULL, the default) this is one untaken scalar branch per interval.
+struct SbrTraceRec {
+    const SbrBuf& b;
+    const double* meta_lds;       // the lane's parked steps/status/done word
+    int64_t env;                  // index of the lane's env in the handle
+    SBR_DEV void pid(int iv, double e, double ie, double dcv) const {
+        if (__builtin_expect(b.trace != nullptr, 0)) {
+            const int64_t steps = (int64_t)((int)(*meta_lds) >> 4);
+            if (env < b.n_trace && steps < b.trace_cap) {
+                double* rec = b.trace + (steps * SBR_NTRACE) * b.n_trace + env;
+                if (iv == 0) {
+                    rec[SBR_TR_E_EC_FIRST * b.n_trace] = e; rec[SBR_TR_IE_EC_FIRST * b.n_trace] = ie; rec[SBR_TR_DCV_EC_FIRST * b.n_trace] = dcv;
+                }
+                rec[SBR_TR_E_EC * b.n_trace] = e; rec[SBR_TR_IE_EC * b.n_trace] = ie; rec[SBR_TR_DCV_EC * b.n_trace] = dcv;
+            }
+        }
+    }
+};
+
 template <typename OutT, typename ActT, int BLK, bool OCI>
 __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
                                                       const ActT* __restrict__ action, uint32_t flags, OutT* __restrict__ obs,
@@ -439,6 +498,9 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     double x[SBR_NX];
     SbrCtl c;
     SBR_STAMP(0, false);
+#if SBR_WARM_MODE == 2
+    const uint32_t warm_token = sbr_warm_kernarg_issue();
+#endif
     // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
     // in logical order, whose rows depend on t: a second, dependent round trip)
     load_x(b, i0, l, x);
@@ -446,13 +508,29 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     const double meta0 = CTRL(R_META);
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
+    double ring[SBR_KLA_HIST];
 #pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) {               // physical slot order, slots 0..7 twice
-        const double v = CTRL(R_RING0 + j);
-        my[j * 64] = v;
-        if (j < SBR_RING2 - SBR_KLA_HIST) my[(SBR_KLA_HIST + j) * 64] = v;
+    for (int j = 0; j < SBR_KLA_HIST; ++j) ring[j] = CTRL(R_RING0 + j);           // physical slot order
+    const double ret0 = CTRL(R_RET);
+#if SBR_WARM_MODE == 1
+    sbr_warm_kernarg();                       // in the shadow of the global loads above
+#elif SBR_WARM_MODE == 2
+    sbr_warm_kernarg_wait(warm_token);
+#endif
+#pragma unroll
+    for (int j = 0; j < SBR_KLA_HIST; ++j) {               // parked in slot order, slots 0..7 twice
+        my[j * 64] = ring[j];
+        if (j < SBR_RING2 - SBR_KLA_HIST) my[(SBR_KLA_HIST + j) * 64] = ring[j];
     }
-    my[SBR_RING2 * 64] = CTRL(R_RET); my[(SBR_RING2 + 1) * 64] = meta0;
+    my[SBR_RING2 * 64] = ret0; my[(SBR_RING2 + 1) * 64] = meta0;
+    // The controller rows are only read inside the `not done` branch below, and the compiler SINKS such a load into the branch:
+    // issued after the batch above has returned, it is a second, fully exposed memory round trip (~0.3 us; seen in the ISA of
+    // rounds 2-3 as one global_load behind the branch).  Passing the values through an empty asm statement here pins their loads
+    // above it, into the one batch.
+    double a0p = a0, a1p = a1;
+#if SBR_PIN_LOADS
+    asm volatile("" : "+v"(c.so_m1), "+v"(c.sno_m1), "+v"(c.ie_do), "+v"(c.ie_ec), "+v"(c.ec_last), "+v"(c.t), "+v"(a0p), "+v"(a1p));
+#endif
     SbrX6Lds x6{my + (SBR_RING2 + 2) * 64};
     if (OCI) my[SBR_NPARK * 64] = CTRL(R_KSUM);           // only this reward keeps the running sum of Kla
     x6.put(x);
@@ -470,7 +548,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
         SBR_STAMP(2, false);
-        sbr_run_intervals<true>(p, c, x, a0, a1, x6);
+        const SbrTraceRec tr{b, my + (SBR_RING2 + 1) * 64, i0 + l};
+#ifndef SBR_STEP_LOOP
+#define SBR_STEP_LOOP true
+#endif
+        sbr_run_intervals<SBR_STEP_LOOP>(p, c, x, a0p, a1p, x6, tr);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
         SbrHistLds hs{tail0, kla_before, 0.0, false};
         x6.get(xa6);
@@ -516,7 +598,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
             rec[SBR_TR_KLA * b.n_trace] = c.knew[c.n_new > 1 ? 1 : 0]; rec[SBR_TR_EC * b.n_trace] = c.ec_last;
             rec[SBR_TR_REWARD * b.n_trace] = r; rec[SBR_TR_DONE * b.n_trace] = dn ? 1.0 : 0.0;
             rec[SBR_TR_U_DO * b.n_trace] = c.u_do; rec[SBR_TR_U_EC * b.n_trace] = c.u_ec;
-            rec[SBR_TR_E_EC * b.n_trace] = c.e_ec; rec[SBR_TR_IE_EC * b.n_trace] = c.ie_ec; rec[SBR_TR_DCV_EC * b.n_trace] = c.dcv_ec;
+            // (e_EC, ie_EC, dcv_EC of the interval(s): written by SbrTraceRec::pid as the PIDs ran)
             // module_reward_EQIOCI.py:60-112: EQI2, and the cost terms over their maxima (Kla = 240, EC = 0.0005 throughout)
             const double ae2 = rp.ae * p.inv_ae_max, ec2 = rp.ec * p.inv_ec_max;
             rec[SBR_TR_R_EQI * b.n_trace] = rp.eqi2; rec[SBR_TR_R_OCI * b.n_trace] = ae2 + ec2;
@@ -580,7 +662,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
         if (finished) continue;
         double t_obs;
         bool dn;
-        sbr_run_intervals<false>(p, c, x, (double)a0, (double)a1, x6);
+        sbr_run_intervals<false>(p, c, x, (double)a0, (double)a1, x6, SbrNoTrace{});
         x6.get(xa6);
         SbrHistReg hs{hist};
         const double r = sbr_finish_step<OCI, SbrHistReg, false>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
@@ -937,7 +1019,8 @@ static void launch_step(sbr_env* e, const void* action, void* obs, void* state, 
 
 extern "C" {
 
-const char* sbr_version(void) { return "sbr_amd 0.1.0 (gfx950, fp64 RK4)"; }
+const char* sbr_version(void) { return "sbr_amd 0.4.0 (gfx950, fp64 RK4)"; }
+int sbr_abi_version(void) { return SBR_ABI_VERSION; }
 
 int sbr_default_config(sbr_config* c) {
     if (!c) return SBR_ERR_INVALID;
@@ -1122,9 +1205,12 @@ int sbr_reset_carry(sbr_env* e, uint64_t seed, const int32_t* scenario, const do
     return reset_impl(e, true, seed, scenario, rnd, influent, mask, obs, stream);
 }
 
-int sbr_set_trace(sbr_env* e, double* buf, int64_t n_envs, int64_t capacity) {
+int sbr_set_trace(sbr_env* e, double* buf, int64_t n_envs, int64_t capacity, int32_t record_width) {
     if (!e || (buf && (n_envs <= 0 || n_envs > e->n || capacity <= 0)))
         return fail(e, SBR_ERR_INVALID, "sbr_set_trace: need 0 < n_envs <= N and capacity > 0");
+    if (buf && record_width != SBR_NTRACE)
+        return fail(e, SBR_ERR_INVALID, "sbr_set_trace: record_width " + std::to_string(record_width) + " != SBR_NTRACE " +
+                                            std::to_string(SBR_NTRACE) + " of this library (caller built against another header?)");
     e->buf.trace = buf; e->buf.n_trace = buf ? n_envs : 0; e->buf.trace_cap = buf ? capacity : 0;
     return SBR_OK;
 }

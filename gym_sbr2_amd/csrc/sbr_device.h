@@ -427,7 +427,6 @@ struct SbrCtl {
     int st_new;               // SBR_ST_* bits raised by this call
     double span;              // t_range[-1] - t_range[0] of the last interval
     int rows;                 // len(t_range) of the last interval: 9 or 10
-    double e_ec, dcv_ec;      // e_EC[-1], dcv_EC[-1] of the last interval (:1918-1921): only the trajectory export reads them
 };
 // the diagnostics sbr_reward appends to its four lists (module_reward_EQIOCI.py:109-112), before normalisation
 struct SbrRewardParts { double eqi2, ae, ec; };
@@ -478,15 +477,19 @@ SBR_DEV int sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX]) {
 
 // One control interval: Sim_aero_rxn :1877-1963 / Sim_anaero_rxn :1965-2051, run_*_step :1331-1419.
 // xs6 receives the interval's start values of the xdot components.
-template <typename X6>
-SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& xs6, bool aerobic) {
+// TR: where the NO3-PID's e / ie / dcv of every interval go (trajectory export; SbrNoTrace for kernels without one).
+struct SbrNoTrace { SBR_DEV void pid(int, double, double, double) const {} };
+template <typename X6, typename TR>
+SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& xs6, bool aerobic, const TR& tr) {
     const double t0 = c.t, t1 = t0 + p.t_delta;
     const double span = t1 - t0;
     // len(t_range) = int(span/dt): 9 or 10 with the fp rounding of (t+t_delta)-t (:1339, :1384).  Exact for every span:
     // the two thresholds decide the values a valid t can produce, anything else takes the IEEE division.
-    if (span >= p.rows10_min) c.rows = 10;             // min(int(span/dt), SBR_KLA_HIST): the quotient is monotonic in span
-    else if (span >= p.rows9_min) c.rows = 9;
-    else {
+    // (Written with selects, like the clamps below: every `if` of this function used to compile to an s_cbranch_execz over a
+    // handful of instructions, and a taken branch costs a single resident wave an instruction-buffer refill - more than the
+    // instructions it skips.)
+    c.rows = span >= p.rows10_min ? 10 : 9;            // min(int(span/dt), SBR_KLA_HIST): the quotient is monotonic in span
+    if (__builtin_expect(!(span >= p.rows9_min), 0)) {
         c.rows = (int)(span / p.dt);
         c.rows = c.rows < 2 ? 2 : (c.rows > SBR_KLA_HIST ? SBR_KLA_HIST : c.rows);   // bounded even if t was injected as garbage
     }
@@ -495,22 +498,31 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     // but the integral keeps winding with set-point 0 (:1974-1997).
     const double e = (aerobic ? c.u_do : 0.0) - c.so_m1;
     const double edt = e * p.dt;
-    c.ie_do = c.ie_do + edt;
-    double kla = __builtin_fma(p.Kc_DO, e, p.KcI_DO * c.ie_do);
+    const double ie_do1 = c.ie_do + edt;
+    double kla = __builtin_fma(p.Kc_DO, e, p.KcI_DO * ie_do1);
     if (deriv) kla = kla + p.KcD_DO * ((c.so_m1 - c.so_m2) * p.inv_dt);
     kla = aerobic ? kla + c.kla_last : 0.0;
-    if (kla > p.Kla_max) { kla = p.Kla_max; c.ie_do = c.ie_do - edt; }
-    if (kla < p.Kla_min) { kla = p.Kla_min; c.ie_do = c.ie_do - edt; }
+    {   // clamp to [Kla_min, Kla_max]; each clamp that fires takes e dt out of the integral again (:1904-1909: two sequential ifs)
+        const bool hi = kla > p.Kla_max;
+        const double k1 = hi ? p.Kla_max : kla, i1 = hi ? ie_do1 - edt : ie_do1;
+        const bool lo = k1 < p.Kla_min;
+        kla = lo ? p.Kla_min : k1;
+        c.ie_do = lo ? i1 - edt : i1;
+    }
     // NO3-PID -> EC (error sign reversed, :2006); forced to 0 in aerobic intervals while its integral winds (:1918-1937)
     const double e2 = c.sno_m1 - c.u_ec;
     const double e2dt = e2 * p.dt;
-    c.e_ec = e2; c.dcv_ec = (c.sno_m1 - c.sno_m2) * p.inv_dt;
-    c.ie_ec = c.ie_ec + e2dt;
-    double ec = __builtin_fma(p.Kc_EC, e2, p.KcI_EC * c.ie_ec);
-    if (deriv) ec = ec + p.KcD_EC * ((c.sno_m1 - c.sno_m2) * p.inv_dt);
+    const double dcv2 = (c.sno_m1 - c.sno_m2) * p.inv_dt;
+    const double ie_ec1 = c.ie_ec + e2dt;
+    double ec = __builtin_fma(p.Kc_EC, e2, p.KcI_EC * ie_ec1);
+    if (deriv) ec = ec + p.KcD_EC * dcv2;
     ec = aerobic ? 0.0 : ec + c.ec_last;
-    if (ec < p.EC_min) { ec = p.EC_min; c.ie_ec = c.ie_ec - e2dt; }
-    else if (ec > p.EC_max) { ec = p.EC_max; c.ie_ec = c.ie_ec - e2dt; }
+    {   // if / elif (:1939-1944, :2030-2035)
+        const bool lo = ec < p.EC_min, hi = !lo && ec > p.EC_max;
+        ec = lo ? p.EC_min : (hi ? p.EC_max : ec);
+        c.ie_ec = (lo || hi) ? ie_ec1 - e2dt : ie_ec1;
+    }
+    tr.pid(c.n_new, e2, c.ie_ec, dcv2);                // trajectory export only (a no-op type otherwise)
     xs6.put(x);
     // wave-uniform choice of the code path only: a lane with ec == 0 computes the same bits in either (sbr_rk4)
     double nold[SBR_NX];
@@ -542,10 +554,12 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
 //                loop the plant is a loop-carried value, ~60 register copies per call).
 // Envs reset together are in lockstep, so the branches are wave-uniform in practice; divergent waves are still correct.
 SBR_DEV int sbr_phase(const SbrPar& p, double t) {
-    return t < p.T3_0 ? 0 : (t <= p.T3_end ? 1 : (t <= p.T4_end ? 2 : (t > p.T4_end ? 3 : -1)));      // -1: t is NaN
+    // = t < T3_0 ? 0 : (t <= T3_end ? 1 : (t <= T4_end ? 2 : (t > T4_end ? 3 : -1))), as a sum of comparisons (no branches);
+    // every comparison is false for a NaN: -1
+    return (t >= p.T3_0 ? 1 : 0) + (t > p.T3_end ? 1 : 0) + (t > p.T4_end ? 1 : 0) - (t == t ? 0 : 1);
 }
-template <bool LOOP, typename X6>
-SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6) {
+template <bool LOOP, typename X6, typename TR>
+SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6, const TR& tr) {
     a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
     a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
     c.n_new = 0; c.st_new = 0;
@@ -557,8 +571,8 @@ SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], 
             const int ph = sbr_phase(p, c.t);
             if (ph > last) {
                 const bool aerobic = (ph & 1) != 0;
-                if (aerobic) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
-                sbr_interval(p, c, x, xs6, aerobic);
+                c.u_do = aerobic ? a0 : 0.0; c.u_ec = aerobic ? 0.0 : a1;
+                sbr_interval(p, c, x, xs6, aerobic, tr);
                 last = ph;
             }
         }
@@ -566,13 +580,13 @@ SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], 
         const int ph = sbr_phase(p, c.t);
         if (ph >= 0) {
             const bool aerobic = (ph & 1) != 0;
-            if (aerobic) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
-            sbr_interval(p, c, x, xs6, aerobic);
+            c.u_do = aerobic ? a0 : 0.0; c.u_ec = aerobic ? 0.0 : a1;
+            sbr_interval(p, c, x, xs6, aerobic, tr);
             const int ph2 = sbr_phase(p, c.t);
             if (__builtin_expect(ph2 > ph, 0)) {
                 const bool aerobic2 = (ph2 & 1) != 0;
-                if (aerobic2) { c.u_do = a0; c.u_ec = 0.0; } else { c.u_ec = a1; c.u_do = 0.0; }
-                sbr_interval(p, c, x, xs6, aerobic2);
+                c.u_do = aerobic2 ? a0 : 0.0; c.u_ec = aerobic2 ? 0.0 : a1;
+                sbr_interval(p, c, x, xs6, aerobic2, tr);
             }
         }
     }

@@ -212,11 +212,11 @@ class SbrOSVec:
         reset.  Returns the buffer [capacity, NTRACE, n_envs] float64 (NaN where nothing was written)."""
         self._trace = torch.full((int(capacity), _capi.NTRACE, int(n_envs)), float("nan"), dtype=torch.float64,
                                  device=self.device)
-        _capi.check(self.lib.sbr_set_trace(self._h, _ptr(self._trace), int(n_envs), int(capacity)), self._h)
+        _capi.check(self.lib.sbr_set_trace(self._h, _ptr(self._trace), int(n_envs), int(capacity), _capi.NTRACE), self._h)
         return self._trace
 
     def disable_trace(self):
-        _capi.check(self.lib.sbr_set_trace(self._h, None, 0, 0), self._h)
+        _capi.check(self.lib.sbr_set_trace(self._h, None, 0, 0, _capi.NTRACE), self._h)
         self._trace = None
 
     # ------------------------------------------------------------------ inspection / parity injection

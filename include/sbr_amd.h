@@ -122,6 +122,11 @@ typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for
 
 /* library / configuration ---------------------------------------------------------------- */
 const char* sbr_version(void);
+/* Bumped whenever a signature, a struct layout or a record width of this header changes.  A consumer compiled against this
+ * header checks sbr_abi_version() == SBR_ABI_VERSION once after loading the library (round 4 = 4: sbr_set_trace takes the
+ * record width, SBR_NTRACE = 34). */
+#define SBR_ABI_VERSION 4
+int sbr_abi_version(void);
 int sbr_default_config(sbr_config* cfg);
 int sbr_device_count(void);          /* HIP devices visible; 0 if none (never throws) */
 /* Host-side helper, no device needed: the reference's control interval has len(t_range) = int(((t + t_delta) - t)/dt) output
@@ -172,12 +177,16 @@ int sbr_reset_carry(sbr_env* env, uint64_t seed, const int32_t* scenario, const 
  * dcv_EC (:1918-1926, :2006-2014) and the four diagnostics sbr_reward appends (module_reward_EQIOCI.py:109-112):
  * EQI2, OCI2 = AE_OCI2 + EC_OCI2, AE_OCI2, EC_OCI2; then what a consumer needs to rebuild the reference's sub-interval rows
  * (sbr_eval_substeps): the number of control intervals the call ran (1, or 2 on a phase-boundary call) and the Kla / EC of
- * the FIRST of them (equal to SBR_TR_KLA / SBR_TR_EC when the call ran one). */
-#define SBR_NTRACE 31
+ * the FIRST of them (equal to SBR_TR_KLA / SBR_TR_EC when the call ran one); and (round 4) the NO3-PID's e_EC, ie_EC, dcv_EC
+ * of that FIRST interval too: the reference appends to these three lists once per INTERVAL (:1918-1926, :2006-2014), so a
+ * phase-boundary call contributes two entries each (equal to SBR_TR_E_EC / _IE_EC / _DCV_EC when the call ran one).
+ * record_width must be SBR_NTRACE of the header the caller was compiled against: the record grew from 28 to 31 to 34 doubles
+ * over the rounds, and a buffer sized for an older width would be overrun silently - a mismatch is SBR_ERR_INVALID. */
+#define SBR_NTRACE 34
 enum { SBR_TR_T = 0, SBR_TR_X0 = 1, SBR_TR_KLA = 15, SBR_TR_EC, SBR_TR_REWARD, SBR_TR_DONE, SBR_TR_U_DO, SBR_TR_U_EC,
        SBR_TR_E_EC, SBR_TR_IE_EC, SBR_TR_DCV_EC, SBR_TR_R_EQI, SBR_TR_R_OCI, SBR_TR_R_AE, SBR_TR_R_EC,
-       SBR_TR_N_IV, SBR_TR_KLA_FIRST, SBR_TR_EC_FIRST };
-int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity);
+       SBR_TR_N_IV, SBR_TR_KLA_FIRST, SBR_TR_EC_FIRST, SBR_TR_E_EC_FIRST, SBR_TR_IE_EC_FIRST, SBR_TR_DCV_EC_FIRST };
+int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity, int32_t record_width);
 
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
  * one (at phase boundaries two) control interval(s) of RK4, reward, observations, and on the last
