@@ -71,10 +71,18 @@ SIMDS = 1024
 PRIME_SECONDS = 0.3                    # untimed: brings the GPU to steady clocks before warm-up and timing
 # phase schedule of an episode in calls (tests/golden/constants.npz): anoxic 46 intervals, aerobic 190, anoxic 171, aerobic 1
 ANOXIC_CALLS = [(0, 46), (235, 405)]   # calls whose interval doses carbon under a random NO3 set-point (boundary calls +-1)
-# the reference itself, measured in the build container by the survey: NOT this box, stated as such
-REFERENCE_CPU = {"value": 1880.0, "unit": "env-steps/s", "cores": 1, "value_8_processes": 14800.0,
-                 "hardware": "survey container, Intel Xeon @ 2.60 GHz, 8 logical cores (not the GPU box)",
-                 "what": "the unmodified Python reference (SbrOS, SciPy LSODA), one env per process, BASELINE.md section 2"}
+def reference_cpu():
+    """The Python reference itself, timed by oracle/time_reference.py in the BUILD CONTAINER (the reference cannot travel to the
+    GPU box) and committed as profiles/reference_cpu_timing.json: read here, never measured or imported by this file."""
+    path = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return {"value": None, "note": "profiles/reference_cpu_timing.json is missing: run oracle/time_reference.py in the build container"}
+    return {"value": rec["value"], "unit": rec["unit"], "cores": rec["cores"], "value_all_cores": rec["value_all_cores"],
+            "cores_all": rec["cores_all"], "hardware": rec["hardware"] + " (build container, NOT the GPU box)",
+            "versions": rec["versions"], "what": rec["what"], "file": "profiles/reference_cpu_timing.json",
+            "script": "oracle/time_reference.py"}
 
 
 def cpu_baseline(n_envs=16384, calls=463, physical=True):
@@ -114,7 +122,7 @@ def cpu_baseline(n_envs=16384, calls=463, physical=True):
                       % (n_envs, calls, cores),
             "single_thread": {"value": best1, "unit": "env-steps/s", "cores": 1,
                               "sample": "%d envs x %d step() calls of the same workload on one thread, best of 2" % (n1, calls)},
-            "reference": REFERENCE_CPU}
+            "reference": reference_cpu()}
 
 
 def pmc_record(lib_hash, profiles_dir=None):
@@ -405,10 +413,20 @@ def main():
     elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
     fence()                                     # a collective's own latency is not part of the K steps
     gc.enable()
+    rank_elapsed, rank_devices = [elapsed], ["cuda:%d %s" % (dev_index, torch.cuda.get_device_name(dev))]
     if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # one small all-gather AFTER the timed region: every rank's own time and device, so that the line says whether RCCL saw
+        # N ranks on N devices and how skewed they were; `value` uses the MAX
+        ws = dist.get_world_size()
+        mine = torch.tensor([elapsed, float(dev_index), float(rank)], dtype=torch.float64, device=dev)
+        allr = torch.empty(ws * 3, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(ws, 3).cpu()
+        rank_elapsed = [float(v) for v in allr[:, 0]]
+        names = [None] * ws
+        dist.all_gather_object(names, torch.cuda.get_device_name(dev))
+        rank_devices = ["cuda:%d %s" % (int(allr[r, 1]), names[r]) for r in range(ws)]
+        elapsed = max(rank_elapsed)
 
     resets_timed = state["episode"] - episodes_before
     # dominant kernel: device time of the step launches of the timed region, from events on the launch stream
@@ -425,9 +443,11 @@ def main():
     rec, traffic_note = pmc_record(loaded_library_hash())
     if rec and n_local != rec.get("envs_per_launch", 65536):
         rec, traffic_note = None, "the committed PMC profile is of %d envs per launch, this run has %d" % (rec.get("envs_per_launch", 65536), n_local)
+    episode = None          # whole-episode launch time of the committed kernel trace of THIS library (hash-matched like traffic)
     if rec and not fused and args.workload == "config2":
         traffic = rec["hbm_bytes_per_launch"]
         valu_per_wave = rec.get("valu_insts_per_wave")
+        episode = rec.get("kernel_trace")
         traffic_note = ("bytes per launch, a committed constant (%s, measured on this library: %.0f B per env-step vs %d algorithmic; "
                         "the internal layout also carries the Kla ring and bookkeeping rows, every byte moves once)"
                         % (rec["_file"], rec["hbm_bytes_per_env_step"], ALGO_BYTES_PER_ENV_STEP))
@@ -482,6 +502,11 @@ def main():
                    "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
                    "collective_backend": ("none" if not dist_up else "nccl (RCCL)" if backend == "nccl" else
                                           "gloo - REHEARSAL: %d ranks share %d GPU(s), not a scaling measurement" % (world, ndev)),
+                   "ranks": dist.get_world_size() if dist_up else 1,
+                   "backend_reported": dist.get_backend() if dist_up else None,
+                   "rank_elapsed_ms": [t * 1e3 for t in rank_elapsed],
+                   "rank_skew_ms": (max(rank_elapsed) - min(rank_elapsed)) * 1e3,
+                   "rank_devices": rank_devices,
                    "allgathers_in_timed_region": acct["allgathers"],
                    "allgather_bytes_per_rank": 4 * n_local if dist_up else 0,
                    "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",
@@ -495,6 +520,16 @@ def main():
                      "algorithmic_bytes_per_launch": n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP,
                      "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                      "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
+                     # `frac` is over the launches this run timed - with --steps 20 that is calls 5..24 of an episode: no
+                     # terminal call (settle / draw / idle, ~290 us once per 463 calls), no reset.  `frac_episode` is the same
+                     # 513 B x N over the AVERAGE duration of every k_step launch of the committed rocprofv3 --kernel-trace
+                     # --stats run of whole episodes, attached only for the library that trace was taken on (source hash)
+                     "frac_episode": (n_local * ALGO_BYTES_PER_ENV_STEP / (episode["average_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS
+                                      if episode else None),
+                     "avg_launch_us_episode": episode["average_ns"] * 1e-3 if episode else None,
+                     "frac_episode_source": ("%s: %d k_step launches, average %.0f ns (committed constant, measured on this library)"
+                                             % (episode["file"], episode["calls"], episode["average_ns"])) if episode else
+                                            "no committed kernel trace of this library and batch size",
                      "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
                                          "host_in_end_of_episode": acct["end_of_episode_ms"],
                                          "host_in_reset_issue": acct["reset_issue_ms"],

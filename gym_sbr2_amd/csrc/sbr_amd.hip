@@ -81,13 +81,18 @@ SBR_DEV void st_out(T* p, T v) {
 #endif
 }
 typedef unsigned int sbr_u32x4 __attribute__((ext_vector_type(4)));
+// The sc1 modifier has no builtin for a 16-byte store, hence inline assembly - and inline assembly is invisible to the
+// compiler's hazard recognizer: on gfx940+ a VMEM store of more than 64 bits reads its data registers for two more cycles, and a
+// VALU instruction that overwrites them inside that window corrupts the stored value (seen in round 4, once the stores were
+// issued back to back: the 64-bit address of the NEXT store was formed in the low half of the data registers of the previous
+// one).  The s_nop supplies the two wait states the compiler would have inserted for a store it knows.
 SBR_DEV void st_out16(sbr_u32x4* p, sbr_u32x4 v) {
 #if SBR_ST_MODE == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #elif SBR_ST_MODE == 2
     __builtin_nontemporal_store(v, p);
 #elif SBR_ST_MODE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #else
     *p = v;
 #endif
@@ -390,23 +395,90 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
     const uint32_t lane = l & 63u;
     char* wdst = reinterpret_cast<char*>(rows + (size_t)(l & ~63u) * NV);
     if (wide && (reinterpret_cast<uintptr_t>(wdst) & 15u) == 0) {
+        asm volatile("" ::: "memory");                         // see store_rows2: the staging stores must not overtake the parked loads
         OutT* mine = reinterpret_cast<OutT*>(stage + lane * RB);
 #pragma unroll
         for (int k = 0; k < NV; ++k) mine[k] = v[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int NR = (CH + 63) / 64;
+        sbr_u32x4 ch[NR];                                      // every chunk into registers first, then the stores (see store_rows2)
 #pragma unroll
-        for (int r = 0; r * 64 < CH; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int c = r * 64 + (int)lane;
-            if ((r + 1) * 64 <= CH || c < CH)
-                st_out16(reinterpret_cast<sbr_u32x4*>(wdst + c * 16), *reinterpret_cast<const sbr_u32x4*>(stage + c * 16));
+            if ((r + 1) * 64 <= CH || c < CH) ch[r] = *reinterpret_cast<const sbr_u32x4*>(stage + c * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CH || c < CH) st_out16(reinterpret_cast<sbr_u32x4*>(wdst + c * 16), ch[r]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
         for (int k = 0; k < NV; ++k) rows[(size_t)l * NV + k] = v[k];
+    }
+}
+
+// Two row sets at once (observation rows first, state rows behind them in the staging region): stage both, ONE wave barrier,
+// read every 16-byte chunk into registers, then issue the stores.  The stores are inline assembly with a memory clobber (the
+// sc1 modifier has no builtin for 16 bytes), which the compiler will not move an LDS read across: read-store-read-store cost
+// one exposed LDS round trip per chunk (nine per call until round 4).  `stage` must hold 64 (RB_A + RB_B) bytes.
+template <typename OutT, int NA, int NB>
+SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, uint32_t l, char* stage, bool wide,
+                         const OutT (&va)[NA], const OutT (&vb)[NB]) {
+    constexpr int RA = NA * (int)sizeof(OutT), RBB = NB * (int)sizeof(OutT);
+    constexpr int CA = 64 * RA / 16, CB = 64 * RBB / 16;         // 16-byte chunks per wave
+    constexpr int NRA = (CA + 63) / 64, NRB = (CB + 63) / 64;
+    const uint32_t lane = l & 63u;
+    char* wa = reinterpret_cast<char*>(rows_a + (size_t)(l & ~63u) * NA);
+    char* wb = reinterpret_cast<char*>(rows_b + (size_t)(l & ~63u) * NB);
+    if (wide && ((reinterpret_cast<uintptr_t>(wa) | reinterpret_cast<uintptr_t>(wb)) & 15u) == 0) {
+        // The staging region is the wave's parking space, whose slots were read as float64 just before: to the compiler's
+        // type-based alias analysis a float32 store and a float64 load never alias, so without this barrier it may hoist the
+        // staging stores above those loads (seen in round 4: rows 27.. of the float32 outputs held parked values).
+        asm volatile("" ::: "memory");
+        char* sa = stage;
+        char* sb = stage + 64 * RA;
+        OutT* ma = reinterpret_cast<OutT*>(sa + lane * RA);
+        OutT* mb = reinterpret_cast<OutT*>(sb + lane * RBB);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) ma[k] = va[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) mb[k] = vb[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sbr_u32x4 ca[NRA], cb[NRB];
+#pragma unroll
+        for (int r = 0; r < NRA; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CA || c < CA) ca[r] = *reinterpret_cast<const sbr_u32x4*>(sa + c * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CB || c < CB) cb[r] = *reinterpret_cast<const sbr_u32x4*>(sb + c * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < NRA; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CA || c < CA) st_out16(reinterpret_cast<sbr_u32x4*>(wa + c * 16), ca[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int c = r * 64 + (int)lane;
+            if ((r + 1) * 64 <= CB || c < CB) st_out16(reinterpret_cast<sbr_u32x4*>(wb + c * 16), cb[r]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) rows_a[(size_t)l * NA + k] = va[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) rows_b[(size_t)l * NB + k] = vb[k];
     }
 }
 
@@ -615,15 +687,24 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     if (done) st_out(&(done + i0)[l], (uint8_t)(dn ? 1 : 0));
     const bool wide = __builtin_amdgcn_ballot_w64(true) == ~0ull;      // all 64 lanes of the wave hold an env
     char* stage = reinterpret_cast<char*>(wave_lds);
-    if (obs) {
-        OutT o[SBR_NOBS];
+    // both row sets fit the wave's staging region together when they are float32 (64 x (72 + 60) = 8448 of 13312 bytes)
+    constexpr bool kBoth = 64 * (SBR_NOBS + SBR_NSTATE) * (int)sizeof(OutT) <= NSLOT * 64 * (int)sizeof(double);
+    if (kBoth && obs && state) {
+        OutT o[SBR_NOBS], sv[SBR_NSTATE];
         sbr_write_obs<OutT>(o, 1, t_obs, x, xa6, x);
-        store_rows<OutT, SBR_NOBS>(obs + i0 * SBR_NOBS, l, stage, wide, o);
-    }
-    if (state) {
-        OutT sv[SBR_NSTATE];
         sbr_write_state<OutT>(sv, 1, t_obs, x);
-        store_rows<OutT, SBR_NSTATE>(state + i0 * SBR_NSTATE, l, stage, wide, sv);
+        store_rows2<OutT, SBR_NOBS, SBR_NSTATE>(obs + i0 * SBR_NOBS, state + i0 * SBR_NSTATE, l, stage, wide, o, sv);
+    } else {
+        if (obs) {
+            OutT o[SBR_NOBS];
+            sbr_write_obs<OutT>(o, 1, t_obs, x, xa6, x);
+            store_rows<OutT, SBR_NOBS>(obs + i0 * SBR_NOBS, l, stage, wide, o);
+        }
+        if (state) {
+            OutT sv[SBR_NSTATE];
+            sbr_write_state<OutT>(sv, 1, t_obs, x);
+            store_rows<OutT, SBR_NSTATE>(state + i0 * SBR_NSTATE, l, stage, wide, sv);
+        }
     }
     SBR_STAMP(6, false);                      // output stores issued
     SBR_STAMP(7, true);                       // every store acknowledged

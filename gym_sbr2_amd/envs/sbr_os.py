@@ -9,10 +9,12 @@ The class derives from `gym.Env` when gym is importable (as upstream, :99), else
 (`gym_sbr2_amd._gymcompat`); either way it speaks the reference's OLD gym API generation: reset() returns the observation only
 and step() the reference's own 5-tuple.
 
-Outputs are float64 like the reference's.  Differences, all deliberate: state lives on the GPU
-instead of module globals (so several instances can coexist), the influent noise comes from an
-explicit `seed`/`rnd` instead of the global numpy RNG, and the 18 lists of `trajectory()` are
-sampled once per step() call (see its docstring).
+Outputs are float64 like the reference's.  State lives on the GPU instead of module globals (so several instances can
+coexist).  The influent noise of `reset()` comes from where the reference takes it - `np.random.randn(48)` on the host
+(buffer_tank3.py:68, drawn inside reset(), gym_SBR_oneshot.py:180) - unless the instance was given a `seed` (then a Philox
+stream on the device, keyed by seed + episode count) or the caller passes `rnd` / `influent`: code written against the
+reference controls an episode with `np.random.seed(k); env.reset()`, and that gives the reference's plant of seed k here
+too.  The 18 lists of `trajectory()` hold one entry per step() call, or with `dense=True` the reference's own entries.
 """
 import numpy as np
 import torch
@@ -43,10 +45,25 @@ def _hermite(nodes, slopes, span, tau):
     return out + h * ((u + 1) * lm ** 2 * slopes[m - 1] + u * l0 ** 2 * slopes[m] + (u - 1) * lp ** 2 * slopes[m + 1])
 
 
+def reference_randn(scenario):
+    """The 48 standard normals of the influent draw, taken from the global NumPy generator exactly as the reference's
+    buffer_tank() consumes it: every scenario block except 0 calls np.random.randn(48) TWICE and uses the second vector
+    (buffer_tank3.py:206 + :224, ..., :971 + :989 for scenario 6, which SbrOS.reset uses; scenario 0, which SbrEnv2.reset uses,
+    draws once, :68).  After np.random.seed(k) the generator is therefore left where the reference leaves it."""
+    rnd = np.random.randn(48)
+    if int(scenario) != 0:
+        rnd = np.random.randn(48)
+    return rnd
+
+
 class SbrOS(_gym.Env):
     metadata = {"render.modes": ["human"]}                      # :101
 
-    def __init__(self, device=0, seed=None, reward=None):
+    def __init__(self, device=0, seed=None, reward=None, rng=None):
+        """rng: where reset() takes the 48 standard normals of the influent draw from when the caller passes neither `rnd` nor
+        `influent`.  "numpy" - `np.random.randn(48)` on the host, once per reset, exactly the reference's draw
+        (buffer_tank3.py:68): `np.random.seed(k)` before reset() selects the episode, as with the reference.  "philox" - drawn on
+        the device from `seed` + episode count.  Default: "numpy", or "philox" when a `seed` is given."""
         # the reference declares stale spaces (:106-113); these are the real ones of step()
         self.action_space = _gym.box([0.0, 0.0], [8.0, 15.0])
         self.observation_space = _gym.box(np.full(18, -np.inf), np.full(18, np.inf))
@@ -55,13 +72,24 @@ class SbrOS(_gym.Env):
         views = self._vec.enable_host_io()        # the kernel reads the action from, and writes its outputs to, pinned host memory
         self._act_row, self._obs_row, self._state_row = views[0][0], views[1][0], views[2][0]
         self._reward_view, self._done_view = views[3], views[4]
+        if rng is None:
+            rng = "philox" if seed is not None else "numpy"
+        if rng not in ("numpy", "philox"):
+            raise ValueError('rng must be "numpy" or "philox"')
+        self._rng = rng
         self._seed = seed
         self._episodes = 0
+        self._done = False
         self._rewards, self._states, self._actions = [], [], []
-        self._x_postfill = self._x_prefill = self._influent = None
+        self._start = None                        # device copies of what the dense trajectory export needs from reset()
 
     def seed(self, seed=None):
-        self._seed = seed
+        """Old-gym `env.seed(k)`: seeds the generator reset() draws from - the global NumPy one for rng="numpy" (what a user of
+        the reference does by hand), the instance's Philox key otherwise."""
+        if self._rng == "numpy":
+            np.random.seed(seed)
+        else:
+            self._seed = seed
         return [seed]
 
     def _split(self, obs_row):
@@ -69,22 +97,38 @@ class SbrOS(_gym.Env):
         return o[:9], o[9:]
 
     def reset(self, rnd=None, scenario=None, influent=None, carry_over=False):
-        """rnd: the 48 standard normals buffer_tank3.py:68 would draw (None: drawn on the device from
-        `seed` + episode count); scenario: 0..7 (None = 6, as the reference :180); carry_over: start the new cycle
-        from the state the last one ended in (the reference's disabled x0_new / IV_new, :260-268)."""
+        """rnd: the 48 standard normals buffer_tank3.py:68 would draw (None: drawn as the instance's `rng` says - by default
+        np.random.randn(48), like the reference); scenario: 0..7 (None = 6, as the reference :180); carry_over: start the new
+        cycle from the state the last one ended in (the reference's disabled x0_new / IV_new, :260-268)."""
         seed = (0 if self._seed is None else int(self._seed)) + self._episodes
         self._episodes += 1
+        if rnd is None and influent is None and self._rng == "numpy":
+            rnd = reference_randn(6 if scenario is None else int(scenario))
         self._rewards, self._states, self._actions = [], [], []
+        self._done = False
         self._trace = self._vec.enable_trace(1, 464)
-        self._x_prefill = (self._vec.get_state()[0][:, 0].cpu().numpy() if carry_over
-                           else np.array(list(self._vec.cfg.x0), dtype=np.float64))      # where the fill phase starts
+        x_pre = self._vec.get_state()[0] if carry_over else None      # where the fill phase starts (device tensor, no host sync)
         obs = self._vec.reset(seed=seed, carry_over=carry_over,
                               scenario=None if scenario is None else [int(scenario)],
                               rnd=None if rnd is None else np.asarray(rnd, dtype=np.float64)[None],
                               influent=None if influent is None else np.asarray(influent, dtype=np.float64)[None])
-        self._x_postfill = self._vec.get_state()[0][:, 0].cpu().numpy()       # where the first interval starts (dense trajectory)
-        self._influent = self._vec.influent()[:, 0].cpu().numpy()              # the loading vector, [0] = inflow during the fill
+        # what trajectory(dense=True) replays from: kept as device tensors (two asynchronous copies on the launch stream) and
+        # only brought to the host if a dense trajectory is ever asked for
+        self._start = (x_pre, self._vec.get_state()[0], self._vec.influent())
         return self._split(obs[0].cpu())
+
+    @property
+    def _x_prefill(self):
+        x_pre = self._start[0]
+        return np.array(list(self._vec.cfg.x0), dtype=np.float64) if x_pre is None else x_pre[:, 0].cpu().numpy()
+
+    @property
+    def _x_postfill(self):
+        return self._start[1][:, 0].cpu().numpy()       # where the first interval starts
+
+    @property
+    def _influent(self):
+        return self._start[2][:, 0].cpu().numpy()       # the loading vector, [0] = inflow during the fill
 
     def step(self, action):
         v = self._vec
@@ -96,9 +140,11 @@ class SbrOS(_gym.Env):
         o = self._obs_row.tolist()
         state = self._state_row.copy()
         reward, done = float(self._reward_view[0]), bool(self._done_view[0])
-        self._rewards.append(reward)
-        self._states.append(state)
-        self._actions.append((float(action[0]), float(action[1])))
+        if not self._done:                        # a finished env ignores further calls (and leaves no trace record): keep the
+            self._rewards.append(reward)          # per-call lists of trajectory() the same length as the records
+            self._states.append(state)
+            self._actions.append((float(action[0]), float(action[1])))
+        self._done = done
         return (o[:9], o[9:]), state, reward, done, {}
 
     def get_available_actions(self, pre_action, n_agents, n_action):
@@ -128,7 +174,7 @@ class SbrOS(_gym.Env):
         from .. import _capi as K
         cfg, vec = self._vec.cfg, self._vec
         dt, t_delta, n = cfg.dt, cfg.t_delta, rec.shape[0]
-        out = {k: [] for k in ("t_t", "x_t", "So_t", "Ss_t", "Sno_t", "Snh_t", "u_DO_t", "u_EC_t")}
+        out = {k: [] for k in ("t_t", "x_t", "So_t", "Ss_t", "Sno_t", "Snh_t", "u_DO_t", "u_EC_t", "EC", "e_EC", "ie_EC", "dcv_EC")}
         conc = (("So_t", 8), ("Ss_t", 2), ("Sno_t", 9), ("Snh_t", 10))
 
         def np_(pair):
@@ -149,6 +195,9 @@ class SbrOS(_gym.Env):
             out[name] += rows[:-1, j].tolist()
         out["u_DO_t"] += [0, kla_f] * (rows_f // 2)                    # Kla * int(len(x_out)/len(Kla)) with Kla = [0, k_fill], :320
         out["u_EC_t"] += [0, 0.0] * (rows_f // 2)                      # EC likewise (:321)
+        out["EC"] += [0, 0.0] * (rows_f // 2)                          # EC = [ec, 0] * 126 (:284, :1637, :324)
+        out["e_EC"].append(0.0 - float(x_pre[9]))                      # Sim_filling's one entry: sp 0 - Sno[-1], Sno = [x_in[9]] (:1624)
+        out["ie_EC"].append(0.0); out["dcv_EC"].append(0.0)            # t_start == 0 (:1630-1631); EC = 0 is inside its limits
         if n == 0:
             out["x_t"] = np.vstack(out["x_t"])
             return out
@@ -176,29 +225,37 @@ class SbrOS(_gym.Env):
             xs2, dx2 = np_(vec.eval_substeps(xs1[two, -1], rec[live][two, K.TR_KLA], span_of(t_mid) / cfg.substeps,
                                              ec=rec[live][two, K.TR_EC]))
 
-        def emit(t_start, nodes, slopes, u_do, u_ec):
+        def emit(t_start, nodes, slopes, u_do, u_ec, ec, pid, x_end=None):
             span = span_of(t_start)
             grid = np.linspace(t_start, t_start + t_delta, int(span / dt))          # the reference's t_range, bit for bit
             rows = _hermite(nodes, slopes, span, np.clip(grid - t_start, 0.0, span))
-            rows[0], rows[-1] = nodes[0], nodes[-1]
+            # exact at the nodes; the last row of a call is the state step() returned (the replay closes V, Si, Xi and the
+            # charge balance per substep, step() per interval: equal to rounding, pinned to the record)
+            rows[0], rows[-1] = nodes[0], (nodes[-1] if x_end is None else x_end)
             out["t_t"] += grid[1:].tolist()
             out["x_t"].append(rows[1:])
             for name, j in conc:
                 out[name] += rows[:-1, j].tolist()
             out["u_DO_t"] += [u_do] * (len(grid) - 1)
             out["u_EC_t"] += [u_ec] * (len(grid) - 1)
+            out["EC"] += [ec] * (len(grid) - 1)                       # EC.append once (:1937 / :2025) + len(t_range) - 2 copies (:1957)
+            out["e_EC"].append(pid[0]); out["ie_EC"].append(pid[1]); out["dcv_EC"].append(pid[2])     # one entry per INTERVAL
 
         second = {int(live[j]): i for i, j in enumerate(two)}
         x_last = None
+        pid_first = rec[:, [K.TR_E_EC_FIRST, K.TR_IE_EC_FIRST, K.TR_DCV_EC_FIRST]]
+        pid_last = rec[:, [K.TR_E_EC, K.TR_IE_EC, K.TR_DCV_EC]]
+        terminal_call = (rec[:, K.TR_DONE] == 1.0) & bool(cfg.terminal)      # its record holds the state AFTER settle / draw / idle
         for i, k in enumerate(live):
             k = int(k)
+            x_rec = None if terminal_call[k] else rec[k, K.TR_X0:K.TR_X0 + 14]
             if k in second:
-                emit(t0[k], xs1[i], dx1[i], *setpoints(t0[k], self._actions[k]))
+                emit(t0[k], xs1[i], dx1[i], *setpoints(t0[k], self._actions[k]), first_ec[k], pid_first[k])
                 j = second[k]
-                emit(t0[k] + t_delta, xs2[j], dx2[j], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC])
+                emit(t0[k] + t_delta, xs2[j], dx2[j], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC], rec[k, K.TR_EC], pid_last[k], x_rec)
                 x_last = xs2[j, -1]
             else:
-                emit(t0[k], xs1[i], dx1[i], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC])
+                emit(t0[k], xs1[i], dx1[i], rec[k, K.TR_U_DO], rec[k, K.TR_U_EC], rec[k, K.TR_EC], pid_last[k], x_rec)
                 x_last = xs1[i, -1]
 
         # ---- the done call: settle and draw rows are constant (x before / after the draw, :2322-2323, :2411-2413), then idle
@@ -222,6 +279,7 @@ class SbrOS(_gym.Env):
                 out[name] += x_out1[:-1, j].tolist() + r_idle[:-1, j].tolist()
             out["u_DO_t"] += [out["u_DO_t"][-1]] * (len(t_all) - 1)                 # :1153-1154
             out["u_EC_t"] += [out["u_EC_t"][-1]] * (len(t_all) - 1)
+            out["EC"] += [0] * (len(t_all) - 1)                                     # settle + draw (:2411-2412) and idle (:2593-2594)
         out["x_t"] = np.vstack(out["x_t"])
         return out
 
@@ -233,19 +291,23 @@ class SbrOS(_gym.Env):
 
         Every list has ONE entry per step() call of the running episode, recorded on the device at the end of the call
         (for a call that runs two control intervals: of the second, like the reward).  The reference grows t_t, x_t, the
-        four concentration lists and the two set-point lists by the 8 or 9 rows of LSODA's output grid per interval, and its
-        controller lists (EC, dcv_EC, ie_EC, e_EC) also hold the entries of the fill phase; the fixed-step integrator has
-        no such grid, so those lists are sampled per call here.  reward_t and the four reward diagnostics
-        (module_reward_EQIOCI.py:109-112) are per call in the reference too.  state_t, which the reference leaves empty
-        (its append is commented out, :436), holds the state vector step() returned.
+        four concentration lists, the two set-point lists and EC by the 8 or 9 rows of LSODA's output grid per interval, and
+        its three PID lists (dcv_EC, ie_EC, e_EC) by one entry per INTERVAL, after one for the fill phase; the fixed-step
+        integrator has no such grid, so those lists are sampled per call here - unless dense=True.  reward_t and the four reward
+        diagnostics (module_reward_EQIOCI.py:109-112) are per call in the reference too.  state_t, which the reference leaves
+        empty (its append is commented out, :436), holds the state vector step() returned.
         as_dict=True returns the same arrays by name (plus Kla, the DO controller's output).
-        dense=True returns t_t, x_t, So_t, Ss_t, Sno_t, Snh_t, u_DO_t and u_EC_t on the reference's sub-interval grids instead
-        (`_dense_rows`): 252 rows of the fill phase, 8 or 9 rows per control interval, and after the done call the rows of
-        settle, draw and idle - the reference's lists entry for entry (4767 time points for a whole episode)."""
+        dense=True returns t_t, x_t, So_t, Ss_t, Sno_t, Snh_t, u_DO_t, u_EC_t and (round 4) EC, dcv_EC, ie_EC, e_EC as the
+        reference grows them, entry for entry (`_dense_rows`): 252 rows of the fill phase, 8 or 9 rows per control interval, and
+        after the done call the rows of settle, draw and idle (4767 time points and EC entries for a whole episode); 467 entries
+        in each of the three PID lists - the fill phase's, then one per interval, two for a call that crosses a phase boundary.
+        The last dense row of a call is the state step() returned (pinned to the record; the replayed nodes agree with it to
+        rounding, ~1e-13 relative)."""
         from .. import _capi as K
         n = len(self._rewards)
         rec = self._trace[:n].cpu().numpy()[:, :, 0]
-        rec = rec[np.isfinite(rec[:, K.TR_T])]          # calls made after `done` leave no record (a finished env ignores them)
+        rec = rec[np.isfinite(rec[:, K.TR_T])]          # (step() stops appending once the episode is done: every per-call list
+        assert len(rec) == n == len(self._states)       # has one entry per recorded call)
         x_t = rec[:, K.TR_X0:K.TR_X0 + 14]
         cols = {"t_t": rec[:, K.TR_T], "x_t": x_t, "u_DO_t": rec[:, K.TR_U_DO], "u_EC_t": rec[:, K.TR_U_EC],
                 "state_t": [s.copy() for s in self._states], "So_t": x_t[:, 8], "Ss_t": x_t[:, 2], "EC": rec[:, K.TR_EC],

@@ -37,25 +37,46 @@ def _register_one(reg, name, env_id, entry):
     reg.register(id=env_id, entry_point=entry)
 
 
+def _already_registered(reg, env_id):
+    """Is env_id in the library's registry?  (old gym: registry.env_specs; gymnasium / newer gym: a dict)"""
+    registry = getattr(reg, "registry", None)
+    if registry is None:
+        return False
+    specs = getattr(registry, "env_specs", registry)
+    try:
+        return env_id in specs
+    except TypeError:
+        return False
+
+
 def register_with_gym(strict=False):
-    """Register the ids of this build with gym and/or gymnasium, whichever import (neither is in this image: then only
-    gym_sbr2_amd.make() knows the ids).  Returns {library: [ids registered]}; a library that is not installed is simply absent.
-    A registration that FAILS is never silent: strict=True raises, otherwise the failure is recorded in REGISTRATION_ERRORS
-    and reported as a RuntimeWarning (an odd gym version must not make `import gym_sbr2_amd` unusable)."""
+    """Register the ids of this build with the gym library the env classes derive from (`_gymcompat.LIBRARY`: gym if it
+    imports, else gymnasium; neither is in this image: then only gym_sbr2_amd.make() knows the ids).  Only THAT library: the
+    classes subclass its Env, and gymnasium.make() refuses gym.Env subclasses (and vice versa).  Returns {library: [ids
+    registered]}.  Ids that are already in the library's registry (a second call, e.g. through compat.install_as_gym_SBR())
+    count as registered and are not registered again - an old-API gym raises on a duplicate id.  A registration that FAILS -
+    the library's registration module not importing included - is never silent: strict=True raises, otherwise the failure is
+    recorded in REGISTRATION_ERRORS and reported as a RuntimeWarning (an odd gym version must not make `import gym_sbr2_amd`
+    unusable)."""
+    from . import _gymcompat
     done = {}
     REGISTRATION_ERRORS.clear()
-    for name in ("gym", "gymnasium"):
+    name = _gymcompat.LIBRARY
+    if name is not None:
         try:
             reg = importlib.import_module(name + ".envs.registration")
-        except ImportError:
-            continue
-        done[name] = []
-        for env_id, entry in sorted(_REGISTRY.items()):
-            try:
-                _register_one(reg, name, env_id, entry)
-                done[name].append(env_id)
-            except Exception as exc:          # noqa: BLE001 - reported below, never dropped
-                REGISTRATION_ERRORS[(name, env_id)] = "%s: %s" % (type(exc).__name__, exc)
+        except Exception as exc:              # noqa: BLE001 - not only ImportError: e.g. an old gym under a new numpy
+            reg = None
+            REGISTRATION_ERRORS[(name, "*")] = "import %s.envs.registration: %s: %s" % (name, type(exc).__name__, exc)
+        if reg is not None:
+            done[name] = []
+            for env_id, entry in sorted(_REGISTRY.items()):
+                try:
+                    if not _already_registered(reg, env_id):
+                        _register_one(reg, name, env_id, entry)
+                    done[name].append(env_id)
+                except Exception as exc:          # noqa: BLE001 - reported below, never dropped
+                    REGISTRATION_ERRORS[(name, env_id)] = "%s: %s" % (type(exc).__name__, exc)
     if REGISTRATION_ERRORS:
         msg = "; ".join("%s.register(%r) failed: %s" % (k[0], k[1], v) for k, v in sorted(REGISTRATION_ERRORS.items()))
         if strict:

@@ -335,6 +335,15 @@ def run_episode(M, seed, actions, rnd_override=None):
     rec["traj_Sno_t"] = np.asarray(traj[8], dtype=np.float64)
     rec["traj_Snh_t"] = np.asarray(traj[17], dtype=np.float64)
     rec["traj_t_t"] = np.asarray(traj[0], dtype=np.float64)
+    # the controller lists as the reference grows them (trajectory() -> ..., EC [7], ..., dcv_EC [9], ie_EC [10], e_EC [11]):
+    # EC holds 252 fill-phase entries (:323-324), len(t_range) - 1 entries per control interval (:1937 / :2025 + :1957-1958)
+    # and the zeros of settle / draw / idle (:2411-2412, :2593-2594); the three PID lists hold the fill-phase entry (:1624-1631)
+    # and ONE entry per control interval - two for a call that crosses a phase boundary
+    rec["traj_EC"] = np.asarray(traj[7], dtype=np.float64)
+    rec["traj_dcv_EC"] = np.asarray(traj[9], dtype=np.float64)
+    rec["traj_ie_EC"] = np.asarray(traj[10], dtype=np.float64)
+    rec["traj_e_EC"] = np.asarray(traj[11], dtype=np.float64)
+    rec["traj_u_EC_t"] = np.asarray(traj[3], dtype=np.float64)
     return rec
 
 

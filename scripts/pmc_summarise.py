@@ -88,6 +88,16 @@ for w in ("config2", "config1", "config5", "cycle"):
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, "%s_bench_%s.json" % (tag, w)))
 shutil.copy(one("trace_config2/**/*kernel_stats.csv"), os.path.join(dst, "%s_bench_config2_kernel_stats.csv" % tag))
+KERNEL_TRACE = None          # the k_step row of the --kernel-trace --stats run (whole episodes): bench.py's roofline.frac_episode
+with open(os.path.join(dst, "%s_bench_config2_kernel_stats.csv" % tag)) as f:
+    for r in csv.DictReader(f):
+        if "k_step<" in r["Name"]:
+            KERNEL_TRACE = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
+                            "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "percentage_of_gpu_time": float(r["Percentage"]),
+                            "file": "profiles/%s_bench_config2_kernel_stats.csv" % tag,
+                            "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (1852 steps = four "
+                                       "episodes incl. their terminal calls; priming and warm-up launches included)"}
+            break
 
 fetch, write = counters("pmc_fetch")["FETCH_SIZE"], counters("pmc_write")["WRITE_SIZE"]
 by_kernel_csv(os.path.join(dst, "%s_pmc_fetch_by_kernel.csv" % tag), "FETCH_SIZE_KiB", fetch)
@@ -142,6 +152,7 @@ out = {
                            "note": "x 112 R; 18 ctrl rows R = 144 (t, So[-1], Sno[-1], 2 integrals, EC[-1], return, meta, 10 ring "
                                    "slots); action 8 R; x 88-112 W; 11 ctrl rows W = 88; obs 72 + state 60 + reward 4 + done 1 W"},
     "algorithmic_bytes_per_env_step": 513,
+    "kernel_trace": KERNEL_TRACE,
 }
 try:                                     # the fused rollout: one launch = a whole episode of 463 calls kept in registers
     rk, rkw = pick(fetch, "k_rollout<"), pick(write, "k_rollout<")

@@ -37,3 +37,19 @@ def test_error_falls_as_h_to_the_sixth_and_two_nodes_fall_back_to_the_cubic():
     nodes, slopes = _nodes(f, df, 0.05, 1, ncomp=1)                     # a span with a single substep: cubic through both ends
     mid = _hermite(nodes, slopes, 0.05, np.array([0.0, 0.025, 0.05]))[:, 0]
     assert abs(mid[0] - f(0.0)) < 1e-15 and abs(mid[2] - f(0.05)) < 1e-15 and abs(mid[1] - f(0.025)) < 1e-7
+
+
+def test_numpy_rng_draw_follows_the_reference_call_pattern():
+    """reset() of the reference-shaped classes takes the influent noise from np.random.randn(48) exactly as buffer_tank() does:
+    every scenario block but 0 draws twice and uses the second vector (buffer_tank3.py:206/:224 ... :971/:989), scenario 0 once
+    (:68).  The fixtures hold the vector the reference actually used after np.random.seed(seed)."""
+    import numpy as np
+    from conftest import golden
+    from gym_sbr2_amd.envs.sbr_os import reference_randn
+    e = golden("sbros_const_2_5")
+    np.random.seed(int(e["seed"]))
+    assert np.array_equal(reference_randn(6), e["rnd"])                 # SbrOS.reset: scenario 6, second draw
+    g = golden("sbrv2_cycles")
+    np.random.seed(11)                                                  # oracle/gen_golden.py run_cycle_env(seed=11)
+    for c in range(len(g["rnd"])):
+        assert np.array_equal(reference_randn(0), g["rnd"][c])          # SbrEnv2.reset: scenario 0, one draw per reset

@@ -1108,7 +1108,35 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
     assert abs(d2["x_t"][251][0] - 1.32) < 1e-12 and len(d2["t_t"]) == 252 + int((rows[:3] - 1).sum())
     assert np.abs(d2["x_t"][-1] - env.trajectory(as_dict=True)["x_t"][2]).max() < 1e-9
     # the lists that are per call upstream too are untouched by dense=True
-    assert np.array_equal(d["reward_t"], per_call["reward_t"]) and len(d["EC"]) == 463
+    assert np.array_equal(d["reward_t"], per_call["reward_t"]) and len(per_call["EC"]) == 463
+    # ---- the controller lists as the reference grows them (gym_SBR_oneshot.py:1918-1957, :2006-2045, :320-324)
+    # EC: [0, 0] * 126 over the fill phase, len(t_range) - 1 copies of every INTERVAL's EC (both intervals of a boundary
+    # call), zeros over settle / draw / idle: the reference's list entry for entry
+    ref_EC = e["traj_EC"]
+    assert len(d["EC"]) == len(ref_EC) == n_all
+    dEC = np.array(d["EC"], dtype=np.float64)
+    assert np.array_equal(dEC[:lo], ref_EC[:lo]) and np.array_equal(dEC[lo + n_dense:], ref_EC[lo + n_dense:]) and not dEC[:lo].any()
+    diff = np.abs(dEC[lo:lo + n_dense] - ref_EC[lo:lo + n_dense])
+    assert (diff < 1e-9).mean() > 0.95 and diff.max() <= 5e-4           # saturated at a clamp on almost every interval, equal there
+    assert np.array_equal(dEC[lo:lo + n_dense], np.repeat(dEC[lo + np.concatenate([[0], np.cumsum(rows - 1)[:-1]])], rows - 1))
+    # e_EC, ie_EC, dcv_EC: the fill phase's entry, then ONE per interval = 467 entries (463 calls, 3 of them with two intervals)
+    for key in ("e_EC", "ie_EC", "dcv_EC"):
+        assert len(d[key]) == len(e["traj_" + key]) == 467, key
+    assert d["e_EC"][0] == e["traj_e_EC"][0] == -e["x0_init"][9] and d["ie_EC"][0] == 0.0 and d["dcv_EC"][0] == 0.0
+    # Sno[-1] of interval i is the reference's own to the parity gate (closed loop), e = Sno[-1] - u_EC, dcv = (Sno[-1] - Sno[-2])/dt
+    tol_sno = 1e-5 * np.abs(e["traj_e_EC"][1:] + e["iv_u_EC"]) + 1e-5 * 20.0
+    assert (np.abs(np.array(d["e_EC"][1:]) - e["traj_e_EC"][1:]) <= tol_sno).all()
+    assert np.abs(np.array(d["ie_EC"]) - e["traj_ie_EC"]).max() < 1.2e-5           # the integral carries the gate-level differences
+    dt_ = 0.002 / 24
+    tol_dcv = (tol_sno + np.concatenate([[tol_sno[0]], tol_sno[:-1]])) / dt_
+    assert (np.abs(np.array(d["dcv_EC"][1:]) - e["traj_dcv_EC"][1:]) <= tol_dcv).all()
+    assert abs(d["dcv_EC"][1] - e["traj_dcv_EC"][1]) < 1e-6 * abs(e["traj_dcv_EC"][1])   # (Ss after the fill - x0[9]) / dt: the :1652 quirk
+    # the boundary calls contribute two entries: entry k of the lists belongs to interval k - 1 = (call iv_call[k - 1])
+    two = np.nonzero(e["step_n_intervals"] == 2)[0]
+    assert len(two) == 3
+    for c in two:
+        i1 = int(np.nonzero(e["iv_call"] == c)[0][0])         # first interval of that call
+        assert d["e_EC"][1 + i1] != d["e_EC"][2 + i1] and per_call["e_EC"][c] == d["e_EC"][2 + i1]    # per-call list = the last interval's
     env.close()
 
 
@@ -1443,8 +1471,13 @@ def test_bench_line_contract(force_dist):
     assert c["resets_in_timed_region"] == 0
     if force_dist:
         assert c["allgathers_in_timed_region"] >= 1 and c["allgather_bytes_per_rank"] == 4 * 65536
+        assert c["ranks"] == 1 and c["backend_reported"] == "nccl" and len(c["rank_elapsed_ms"]) == 1 and c["rank_skew_ms"] == 0.0
     else:
         assert c["allgathers_in_timed_region"] == 0 and c["allgather_bytes_per_rank"] == 0
+        assert c["ranks"] == 1 and c["backend_reported"] is None and c["rank_devices"][0].startswith("cuda:0 ")
+    # both roofline figures travel with the line: `frac` of the timed launches, `frac_episode` from the committed kernel trace of
+    # whole episodes of this very library (None, with the reason, when no such trace is committed)
+    assert ("frac_episode" in r) and (r["frac_episode"] is None or 0.1 < r["frac_episode"] <= r["frac"] * 1.1) and r["frac_episode_source"]
     # PMC traffic is a committed constant: present only if profiles/ holds a profile of THIS library (same source hash)
     assert (r["traffic"] is None) or ("committed constant" in r["traffic_unit"] and r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"])
     assert r["traffic"] is not None or r["traffic_unit"]
@@ -1474,3 +1507,233 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu():
     assert abs(d["value"] - 131072 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]      # whole-job aggregate over both ranks
     assert "cpu_baseline" not in d                            # rank 0 at N = 1 only
     assert "sharded over 2 GPUs" in c["workload"] and d["roofline"]["launches_timed"] == 20
+    # the line explains itself: how many ranks the process group had, over which backend, every rank's own
+    # time and device, and the skew between them; `value` is computed from the slowest rank
+    assert c["ranks"] == 2 and c["backend_reported"] == "gloo" and len(c["rank_elapsed_ms"]) == 2 and len(c["rank_devices"]) == 2
+    assert all(dv.startswith("cuda:0 ") for dv in c["rank_devices"])                 # two ranks share the one GPU of this box
+    assert abs(max(c["rank_elapsed_ms"]) - d["ms_per_step"] * 20) < 1e-6 and c["rank_skew_ms"] >= 0.0
+
+
+@pytest.mark.gpu
+def test_numpy_rng_reset_is_the_reference_draw(G, monkeypatch):
+    """code written against the reference controls an episode with `np.random.seed(k); env.reset()` - the
+    influent noise is np.random.randn(48), drawn inside reset() (buffer_tank3.py:68 ... :989, gym_SBR_oneshot.py:180,
+    gym_SBR_env2.py:104).  The reference-shaped classes do the same by default: seed 0 gives the reference's anchors
+    (return -0.8789670883455737, Qw 0.05015591126665638), also through the gym_SBR alias of
+    gym_sbr2_amd.compat, and a seeded instance (Philox on the device) leaves the global generator alone."""
+    import sys
+    from gym_sbr2_amd import _capi
+    e = golden("sbros_const_2_5")
+    assert int(e["seed"]) == 0
+    np.random.seed(0)
+    env = G.make("SBROS-v1")
+    obs = env.reset()                                           # no rnd=, no seed=
+    assert np.allclose(obs[0], e["reset_obs_DO"], rtol=0, atol=1e-6) and np.allclose(obs[1], e["reset_obs_EC"], rtol=0, atol=1e-6)
+    assert np.abs(env._influent[1:] - e["influent_mixed"][1:]).max() < 1e-11          # the reference's influent of seed 0
+    after = np.random.get_state()[1].copy()
+    np.random.seed(0); np.random.randn(48); np.random.randn(48)                        # the reference draws twice for scenario 6
+    assert np.array_equal(after, np.random.get_state()[1])                             # generator left where the reference leaves it
+    total, done, k = 0.0, False, 0
+    while not done:
+        _, _, r, done, _ = env.step([2.0, 5.0])
+        total += r; k += 1
+    assert k == 463 and abs(total / -0.8789670883455737 - 1) < 1e-5
+    qw = float(env._vec.ctrl_row(_capi.C_QW)[0].item())
+    assert abs(qw / 0.05015591126665638 - 1) < 1e-5
+    # a second episode continues the global stream, like a second reset() of the reference
+    np.random.seed(0); np.random.randn(48); np.random.randn(48)
+    st = np.random.get_state()
+    z = [np.random.randn(48), np.random.randn(48)][1]
+    np.random.set_state(st)
+    env.reset()
+    from gym_sbr2_amd.vec_env import load_influent_tables
+    means, stds = load_influent_tables()
+    want = O.OracleBatch(1).mix(means, stds, np.array([6], dtype=np.int32), z[None])
+    assert np.abs(env._influent[1:] - want[0, 1:]).max() < 1e-11
+    env.close()
+    # env.seed(k) of the old gym API seeds that generator
+    env = G.make("SBROS-v1")
+    assert env.seed(0) == [0]
+    obs2 = env.reset()
+    assert obs2 == obs
+    env.close()
+    # an explicitly seeded instance draws on the device and does not touch NumPy's generator
+    np.random.seed(5); before = np.random.get_state()[1].copy()
+    env = G.make("SBROS-v1", seed=3)
+    o3 = env.reset()
+    assert np.array_equal(before, np.random.get_state()[1]) and o3 != obs
+    env.close()
+    # through the alias a user of the reference imports
+    for name in ("gym_SBR", "gym_SBR.envs"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    from gym_sbr2_amd import compat
+    compat.install_as_gym_SBR()
+    from gym_SBR.envs import SbrEnv2, SbrOS
+    np.random.seed(0)
+    env = SbrOS()
+    assert env.reset() == obs
+    env.close()
+    # SBR-v2: scenario 0 draws once (buffer_tank3.py:68); the golden cycles were recorded after np.random.seed(11)
+    g = golden("sbrv2_cycles")
+    np.random.seed(11)
+    e2 = SbrEnv2()
+    for c in range(2):
+        s0 = e2.reset()
+        s1, r1, d1, info = e2.step(g["actions"][c])
+        assert np.abs(s0 - g["reset_state"][c]).max() < 1e-11 and abs(r1 - g["reward"][c]) < 1e-6
+        assert np.allclose(s1, g["state"][c], rtol=1e-6) and abs(e2.diagnostics()["Qw"] / g["Qw"][c] - 1) < 1e-5
+    e2.close()
+    for name in ("gym_SBR", "gym_SBR.envs"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+
+
+@pytest.mark.gpu
+def test_output_rows_equal_the_state_vector_for_both_output_types(G):
+    """Every entry of the `state` rows of sbr_step against [t, x] / x_1_state (gym_SBR_oneshot.py:153) recomputed on the host
+    from sbr_get_state, for float32 and float64 outputs and for both workgroup sizes.  Round 4 found the 16-byte output stores
+    (inline assembly, which the compiler's hazard recognizer cannot see) corrupted once they were issued back to back: the low
+    half of a store's data registers was overwritten by the next store's address arithmetic inside the two-cycle window in
+    which a VMEM store of more than 64 bits still reads them.  The observation rows are covered against the oracle by the
+    episode tests; this one checks ALL rows of a full-size batch."""
+    from gym_sbr2_amd import _capi
+    x1 = np.array([0.5, 1.32, 30, 30, 1500, 150, 3000, 2000, 600, 8, 20, 20, 10, 10, 10])
+    for n in (64, 4096 + 37, 65536):
+        for dt, tol in ((torch.float32, 2e-7), (torch.float64, 1e-14)):
+            env = G.SbrOSVec(n, out_dtype=dt)
+            env.reset(seed=1, scenario=(torch.arange(n, device="cuda") % 8).to(torch.int32))
+            a = torch.rand(n, 2, device="cuda") * torch.tensor([8.0, 15.0], device="cuda")
+            for c in range(2):
+                o, s, r, d = env.step(a)
+                x, ctrl = env.get_state()
+                want = np.concatenate([_np(ctrl[_capi.C_T])[:, None], _np(x).T], axis=1) / x1
+                got = _np(s).astype(np.float64)
+                assert np.abs(got - want).max() <= tol * (1 + np.abs(want).max()), (n, dt, c)
+                assert (np.abs(got - want) <= tol * (1 + np.abs(want))).all(), (n, dt, c)
+                # obs_DO[1..4] = [Xbh/2000, Xba/500, So/8, Snh/10], obs_EC[1..4] = [Ss/30, Xbh/2000, Sno/10, Snh/10] of the same x (:150-156)
+                xs = _np(x).T
+                wo = np.stack([xs[:, 5] / 2000, xs[:, 6] / 500, xs[:, 8] / 8, xs[:, 10] / 10], axis=1)
+                we = np.stack([xs[:, 2] / 30, xs[:, 5] / 2000, xs[:, 9] / 10, xs[:, 10] / 10], axis=1)
+                go = _np(o).astype(np.float64)
+                assert (np.abs(go[:, 1:5] - wo) <= tol * (1 + np.abs(wo))).all() and (np.abs(go[:, 10:14] - we) <= tol * (1 + np.abs(we))).all()
+            env.close()
+
+
+@pytest.mark.gpu
+def test_trace_record_width_and_abi_version(G):
+    """SBR_NTRACE grew 28 -> 31 -> 34 over the rounds; a consumer compiled against an older header would hand
+    sbr_set_trace a buffer that is too small.  The width is now an argument, a mismatch is refused, and the library reports
+    the ABI version of the header it was built from."""
+    import ctypes as C
+    from gym_sbr2_amd import _capi
+    lib = _capi.load()
+    assert lib.sbr_abi_version() == _capi.ABI_VERSION == 4 and _capi.NTRACE == 34
+    env = G.SbrOSVec(8)
+    buf = torch.zeros(4, _capi.NTRACE, 8, dtype=torch.float64, device="cuda")
+    assert lib.sbr_set_trace(env._h, buf.data_ptr(), 8, 4, 31) == -1 and b"record_width" in lib.sbr_last_error(env._h)
+    assert lib.sbr_set_trace(env._h, buf.data_ptr(), 8, 4, _capi.NTRACE) == 0
+    assert lib.sbr_set_trace(env._h, None, 0, 0, 0) == 0                 # switching off needs no width
+    env.close()
+    # the per-call lists of the reference-shaped env stay as long as the records when step() is called after `done`
+    e = golden("sbros_const_2_5")
+    env = G.make("SBROS-v1")
+    env.reset(rnd=e["rnd"])
+    for k in range(463):
+        _, _, _, done, _ = env.step([2.0, 5.0])
+    assert done
+    env.step([2.0, 5.0]); env.step([1.0, 1.0])                          # ignored by the finished env
+    t = env.trajectory()
+    assert all(len(v) == 463 for v in t) and len(env._actions) == 463
+    env.close()
+
+
+@pytest.mark.gpu
+def test_configs4_fused_rollout_at_full_size(G, tables):
+    """BASELINE.json configs[4] at ITS OWN size: ONE sbr_rollout(463) launch over 65536 envs under the bench's
+    physical policy (on-device Philox set-points u_DO ~ U[0, 2.5], u_EC ~ U[0, 15], influent scenarios 4..7).
+      * every env finishes, all returns finite, no env near a pole;
+      * 64-env handles with the same global ids (first, middle and last wavefront) are bit-identical: the fused kernel's
+        arithmetic does not depend on the batch around an env;
+      * a 512-env oracle sample (first, middle, last wavefronts) running the same Philox policy FREE over the whole episode:
+        within 1e-6 of the gate, returns within 1e-10;
+      * the returns equal the sum of rewards of sbr_step replaying the sampled actions (`actions_out`) on the sample."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n, steps, seed, pseed = 65536, 463, 1000, 77
+    cfg = _capi.default_config()
+    cfg.act_DO_max = 2.5                                               # what the on-device policy draws from (bench.py)
+    gid = np.arange(n)
+    scen = (4 + gid % 4).astype(np.int32)
+    env = G.SbrOSVec(n, config=cfg)
+    env.reset(seed=seed, scenario=scen)
+    ret, acts = env.rollout(steps, policy_seed=pseed, return_actions=True)
+    x, ctrl = env.get_state()
+    xn, cn, retn = _np(x), _np(ctrl), _np(ret)
+    assert np.all(cn[_capi.C_DONE] == 1) and np.all(cn[_capi.C_STEPS] == steps) and np.isfinite(retn).all() and np.isfinite(xn).all()
+    st = cn[_capi.C_STATUS].astype(np.int64)
+    assert np.all((st & (_capi.ST_NEAR_POLE | _capi.ST_NONFINITE)) == 0)
+    assert np.array_equal(cn[_capi.C_RETURN], retn)                    # the launch covered the whole episode
+    assert float(_np(acts[:, :, 0]).max()) <= 2.5 and float(_np(acts[:, :, 1]).max()) <= 15.0
+    # ---- 64-env handles with the same global ids: bit for bit
+    for first in (0, n // 2, n - 64):
+        cfg_s = _capi.default_config(); cfg_s.act_DO_max = 2.5
+        small = G.SbrOSVec(64, first_env_id=first, config=cfg_s)
+        small.reset(seed=seed, scenario=scen[first:first + 64])
+        rs = small.rollout(steps, policy_seed=pseed)
+        xs, cs = small.get_state()
+        assert torch.equal(rs, ret[first:first + 64]) and torch.equal(xs, x[:, first:first + 64]) and torch.equal(cs, ctrl[:, first:first + 64])
+        small.close()
+    # ---- oracle sample, free-running with the same Philox policy
+    waves = [0, 1, 2, n // 128, n // 128 + 1, n // 64 - 3, n // 64 - 2, n // 64 - 1]
+    pick = np.concatenate([np.arange(w * 64, w * 64 + 64) for w in waves])
+    assert len(pick) == 512
+    worst_g, worst_r = 0.0, 0.0
+    for w in waves:
+        ids = np.arange(w * 64, w * 64 + 64)
+        p = O.default_params(); p.act_DO_max = 2.5
+        ora = O.OracleBatch(64, params=p, nthreads=8, first_env_id=int(ids[0]))
+        ora.reset(ora.mix(means, stds, scen[ids], ora.normals(seed)))
+        assert np.array_equal(_np(acts[:3, ids[0]:ids[0] + 64]), ora.policy_actions(3, pseed))     # same stream, same float32 actions
+        oret = ora.rollout(steps, pseed)
+        g = gate(xn.T[ids], ora.envs["x"]).max()
+        worst_g, worst_r = max(worst_g, g), max(worst_r, np.abs(retn[ids] - oret).max())
+        assert np.array_equal(st[ids], ora.envs["status"].astype(np.int64))
+        assert np.abs(cn[_capi.C_QW][ids] / ora.envs["qw"] - 1).max() < 1e-9
+    print("configs[4] at 65536 envs, 512-env oracle sample free-running: worst gate %.3e, worst |d return| %.3e" % (worst_g, worst_r))
+    assert worst_g < 1e-6 and worst_r < 1e-10
+    # ---- sbr_step replaying the sampled actions on the first and the last wavefront
+    for first in (0, n - 64):
+        cfg_s = _capi.default_config(); cfg_s.act_DO_max = 2.5
+        rep = G.SbrOSVec(64, first_env_id=first, config=cfg_s, out_dtype=torch.float64)
+        rep.reset(seed=seed, scenario=scen[first:first + 64])
+        tot = torch.zeros(64, dtype=torch.float64, device="cuda")
+        for c in range(steps):
+            _, _, r, _ = rep.step(acts[c, first:first + 64].contiguous())
+            tot += r
+        assert torch.allclose(tot, ret[first:first + 64], rtol=0, atol=1e-12)
+        xr, _ = rep.get_state()
+        assert gate(_np(xr).T, xn.T[first:first + 64]).max() < 1e-6
+        rep.close()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_configs3_shard_of_a_fused_rollout_equals_the_slice_of_the_262144_env_rollout(G):
+    """configs[3] x configs[4]: rank 3 of 8 of a 262144-env batch (32768 envs, first_env_id 98304) runs the fused rollout on its
+    own; the same global ids inside ONE 262144-env rollout give the same returns, plants and controller rows, bit for bit."""
+    from gym_sbr2_amd import ShardedSbrOS, _capi
+    n_global, world, rank, steps = 262144, 8, 3, 463
+    cfg = _capi.default_config(); cfg.act_DO_max = 2.5
+    sh = ShardedSbrOS(n_global, rank=rank, world=world, device=0, config=cfg)
+    n, first = sh.stop - sh.start, sh.start
+    assert (n, first) == (32768, 98304)
+    scen_of = lambda gid: 4 + gid % 4                                  # noqa: E731
+    sh.reset(seed=1000, scenario_of=scen_of)
+    r_sh = sh.rollout(steps, policy_seed=77)
+    cfg_b = _capi.default_config(); cfg_b.act_DO_max = 2.5
+    big = G.SbrOSVec(n_global, config=cfg_b)
+    big.reset(seed=1000, scenario=scen_of(torch.arange(n_global, device="cuda")).to(torch.int32))
+    r_big = big.rollout(steps, policy_seed=77)
+    x_sh, c_sh = sh.env.get_state(); x_big, c_big = big.get_state()
+    assert torch.equal(r_sh, r_big[first:first + n]) and torch.equal(x_sh, x_big[:, first:first + n]) and torch.equal(c_sh, c_big[:, first:first + n])
+    assert bool((c_big[_capi.C_DONE] == 1).all()) and bool(torch.isfinite(r_big).all())
+    sh.close(); big.close()

@@ -30,6 +30,8 @@ def _stand_in(name, fail_on=None, new_keywords=False):
             raise TypeError("register() got an unexpected keyword argument %r" % sorted(kw)[0])
         if id == fail_on:
             raise ValueError("id %s refused" % id)
+        if id in registry:                        # what an old-API gym does (gym.error.Error: Cannot re-register id)
+            raise RuntimeError("Cannot re-register id: %s" % id)
         registry[id] = dict(entry_point=entry_point, **kw)
 
     spaces.Box, registration.register, registration.registry = Box, register, registry
@@ -89,6 +91,40 @@ def test_classes_derive_from_the_library_env_and_register_like_the_reference(fre
     if name == "gymnasium":       # new-protocol checkers off: the classes speak the reference's old API generation
         assert reg["SBROS-v1"]["disable_env_checker"] is True and reg["SBROS-v1"]["order_enforce"] is False
     assert isinstance(compat.box([0, 0], [8, 15]), lib.spaces.Box)
+    # a second call finds the ids in the registry and does not register them again (the stand-in raises on a duplicate)
+    assert registration.register_with_gym(strict=True) == {name: ["SBR-v2", "SBROS-v1"]}
+
+
+def test_only_the_library_the_classes_derive_from_is_registered_with(fresh_package):
+    """With both libraries installed the classes subclass gym.Env (gym is tried first): registering them with gymnasium too
+    would hand gymnasium.make() a class it refuses."""
+    mods = dict(_stand_in("gym"))
+    mods.update(_stand_in("gymnasium", new_keywords=True))
+    compat, envs = fresh_package(mods)
+    from gym_sbr2_amd import registration
+    assert compat.LIBRARY == "gym" and issubclass(envs.SbrOS, mods["gym"].Env)
+    assert registration.register_with_gym(strict=True) == {"gym": ["SBR-v2", "SBROS-v1"]}
+    assert set(mods["gym.envs.registration"].registry) == {"SBROS-v1", "SBR-v2"} and not mods["gymnasium.envs.registration"].registry
+
+
+def test_a_registration_module_that_does_not_import_is_reported(fresh_package, monkeypatch):
+    """Not only ImportError: an old gym under a new numpy dies with AttributeError inside gym.envs.registration; `import
+    gym_sbr2_amd` must survive that and say so."""
+    mods = _stand_in("gym")
+    fresh_package(mods)
+    from gym_sbr2_amd import registration
+    real_import = importlib.import_module
+
+    def broken(name, *a, **k):
+        if name == "gym.envs.registration":
+            raise AttributeError("module 'numpy' has no attribute 'bool8'")
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(registration.importlib, "import_module", broken)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert registration.register_with_gym() == {}
+    assert ("gym", "*") in registration.REGISTRATION_ERRORS and "bool8" in registration.REGISTRATION_ERRORS[("gym", "*")]
+    assert any(issubclass(x.category, RuntimeWarning) for x in w)
 
 
 def test_a_failed_registration_is_reported_not_swallowed(fresh_package):
