@@ -116,15 +116,19 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[
 }
 // INTERNAL controller layout [R_NROWS][N] (the public one of sbr_amd.h is produced by k_export / consumed by k_import):
 //  * the Kla history is a RING: the value of the j-th interval since reset sits in slot (j-1) % 10, where the interval
-//    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten;
-//  * steps, status bits and the done flag share one row (meta = steps*16 + status*2 + done, an integer < 2^31 held in a
-//    double: steps saturate at 2^27 - 1 calls per episode);
+//    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten, and
+//    (round 4) READS three: next to the ring the handle keeps Kla[-1] and the sum of the eight entries before it, from which
+//    the reward's window follows incrementally (SbrHistInc in sbr_device.h);
+//  * steps, the idle-append flag, status bits and the done flag share one row (meta = steps*32 + idle*16 + status*2 + done,
+//    an integer < 2^31 held in a double: steps saturate at 2^26 - 1 calls per episode);
 //  * rows only read when tauD != 0 (So[-2], Sno[-2]), only at the end of an episode (Qw) or only by the operating-cost
 //    reward (the running sum of Kla) come last.
-// Per env-step the step kernel reads 18 rows and writes 11 (232 B) instead of 20 + 24 (352 B).
-enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_RING0,
+// Per env-step the step kernel reads 13 controller rows (t, So[-1], Sno[-1], two integrals, EC[-1], return, meta, Kla[-1], w8,
+// three ring slots) and writes 13 (those minus the three slots, plus So[-2], Sno[-2] and one ring slot): 208 B, where the
+// public layout would take 20 + 24 rows (352 B) and rounds 2-3 took 18 + 11 (232 B).
+enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_KLA_LAST, R_W8, R_RING0,
        R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_KSUM, R_NROWS };
-#define SBR_MAX_STEPS ((1 << 27) - 1)
+#define SBR_MAX_STEPS ((1 << 26) - 1)
 
 SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since reset, from the running time
     double q = __builtin_fma(t - p.T_fill, p.inv_t_delta, 0.5);
@@ -133,10 +137,23 @@ SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since r
     return (int)q;
 }
 SBR_DEV int ring_wrap(int s) { return s >= SBR_KLA_HIST ? s - SBR_KLA_HIST : s; }       // for 0 <= s < 20
-SBR_DEV double meta_pack(int steps, int status, bool done) { return (double)(steps * 16 + status * 2 + (done ? 1 : 0)); }
-SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done) {
+// meta = steps*32 + idle*16 + status*2 + done.  `idle`: the done call of k_step appended one more Kla than t accounts for
+// (Sim_idle's, :2578): the ring's oldest entry then sits one slot further than ring_k(t) says (k_export adds it; a reset, an
+// import or a rollout store the ring in plain order and clear the bit).
+SBR_DEV double meta_pack(int steps, int status, bool done, bool idle = false) {
+    return (double)(steps * 32 + (idle ? 16 : 0) + status * 2 + (done ? 1 : 0));
+}
+SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done, bool& idle) {
     const int v = (int)m;
-    done = (v & 1) != 0; status = (v >> 1) & 7; steps = v >> 4;
+    done = (v & 1) != 0; status = (v >> 1) & 7; idle = (v & 16) != 0; steps = v >> 5;
+}
+SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done) { bool idle; meta_unpack(m, steps, status, done, idle); }
+// the two rows k_step keeps next to the ring (SbrHistInc), from a history in logical order (oldest first, hist[9] = Kla[-1])
+SBR_DEV double hist_w8(const double (&hist)[SBR_KLA_HIST]) {
+    double s = hist[1];
+#pragma unroll
+    for (int j = 2; j <= 8; ++j) s = s + hist[j];
+    return s;
 }
 
 // Rows the step consumes BEFORE the integration.  So[-2], Sno[-2] only feed the derivative term (tauD != 0) and the
@@ -173,10 +190,10 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     double v[SBR_NCTRL], hist[SBR_KLA_HIST];
-    int steps, status; bool done;
+    int steps, status; bool done, idle;
     const double t = CTRL(R_T);
-    load_ring(b, i0, l, ring_k(p, t), hist);
-    meta_unpack(CTRL(R_META), steps, status, done);
+    meta_unpack(CTRL(R_META), steps, status, done, idle);
+    load_ring(b, i0, l, ring_k(p, t) + (idle ? 1 : 0), hist);
     v[SBR_C_T] = t; v[SBR_C_SO_M1] = CTRL(R_SO_M1); v[SBR_C_SO_M2] = CTRL(R_SO_M2);
     v[SBR_C_SNO_M1] = CTRL(R_SNO_M1); v[SBR_C_SNO_M2] = CTRL(R_SNO_M2);
     v[SBR_C_IE_DO] = CTRL(R_IE_DO); v[SBR_C_IE_EC] = CTRL(R_IE_EC); v[SBR_C_EC_LAST] = CTRL(R_EC_LAST);
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
     CTRL(R_SNO_M1) = IN(SBR_C_SNO_M1); CTRL(R_SNO_M2) = IN(SBR_C_SNO_M2);
     CTRL(R_IE_DO) = IN(SBR_C_IE_DO); CTRL(R_IE_EC) = IN(SBR_C_IE_EC); CTRL(R_EC_LAST) = IN(SBR_C_EC_LAST);
     store_ring(b, i0, l, ring_k(p, t), hist);
+    CTRL(R_KLA_LAST) = hist[SBR_KLA_HIST - 1]; CTRL(R_W8) = hist_w8(hist);
     CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN); CTRL(R_KSUM) = IN(SBR_C_KLA_SUM);
     double st = IN(SBR_C_STEPS);
     st = st >= 0.0 ? (st < (double)SBR_MAX_STEPS ? st : (double)SBR_MAX_STEPS) : 0.0;
@@ -323,6 +341,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     store_x(b, i0, l, x);
     store_ctl(b, i0, l, c);
     store_ring(b, i0, l, ring_k(p, c.t), hist);      // k = 0: logical order = slot order
+    CTRL(R_KLA_LAST) = hist[SBR_KLA_HIST - 1]; CTRL(R_W8) = hist_w8(hist);
     CTRL(R_RET) = 0.0; CTRL(R_META) = meta_pack(0, sbr_status_bits(p, x), false); CTRL(R_QW) = 0.0;
     double ksum = 0.0;                               // python's sum() over the list [0, k]*126, left to right
     for (int j = 0; j < p.fill_rows / 2; ++j) ksum = ksum + kla;
@@ -352,32 +371,14 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 // values) are parked in LDS, not in VGPRs and not in scratch: a ~100-cycle round trip instead of a trip through L2/HBM, and
 // the RK4 loop keeps its registers (keeping them in VGPRs was measured: +0.6 us).  Slot j of lane l of wave w is at
 // park[(w*NSLOT + j)*64 + l] (conflict-free).
-// LDS slots of a lane in k_step: the Kla ring as loaded (physical slot order) in 0..9 and AGAIN in 10..17 (slots 0..7), so
-// that entry i of the logical tail, ring slot (kb + i) mod 10, is simply LDS slot kb + i: one per-lane base address and
-// constant offsets, no wrap arithmetic per read; then return, meta, the six xdot start values (and the OCI running sum).
-#define SBR_RING2 (2 * SBR_KLA_HIST - 2)
-#define SBR_NPARK (SBR_RING2 + 2 + SBR_NXD)
-// k_step's Kla history.  Nothing is shifted: the reward reads the eight or nine entries it sums, the new value(s) go
-// straight to their ring slot in HBM.  Only the terminal call needs the whole tail (it rewrites the ring).
-struct SbrHistLds {
-    const double* base;                   // the lane's slot kb: entry i of the tail before this call's appends is base[i * 64]
-    double last, idle; bool idle_pushed;  // old(9) = Kla[-1] is in a register; idle = Sim_idle's append
-    SBR_DEV double old(int i) const { return i == SBR_KLA_HIST - 1 ? last : base[i * 64]; }
-    SBR_DEV double commit_and_window(const SbrCtl& c) const { return sbr_kla_window(c, *this); }
-    SBR_DEV void push(double k) { idle = k; idle_pushed = true; }
-    // the tail after this call's appends (and idle's), oldest first
-    SBR_DEV void tail(const SbrCtl& c, double (&h)[SBR_KLA_HIST]) const {
-        double all[SBR_KLA_HIST + 3];     // old(0..9), knew[0], knew[1], idle - compacted: unused appends are skipped
-#pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST; ++j) all[j] = old(j);
-        all[10] = c.n_new > 0 ? c.knew[0] : idle;
-        all[11] = c.n_new > 1 ? c.knew[1] : idle;
-        all[12] = idle;
-        const int shift = c.n_new + (idle_pushed ? 1 : 0);
-#pragma unroll
-        for (int j = 0; j < SBR_KLA_HIST; ++j) h[j] = shift == 0 ? all[j] : shift == 1 ? all[j + 1] : shift == 2 ? all[j + 2] : all[j + 3];
-    }
-};
+// LDS slots of a lane in k_step: return, meta, the Kla window sum w8, the six xdot start values (and the OCI running sum);
+// the region is sized for the output transposes (64 float64 observation rows: 9216 B = 18 slots).
+#define SBR_PK_RET 0
+#define SBR_PK_META 1
+#define SBR_PK_W8 2
+#define SBR_PK_X6 3
+#define SBR_PK_KSUM (SBR_PK_X6 + SBR_NXD)
+#define SBR_NPARK 20
 
 // One output row per lane (obs: 18 values, state: 15) -> the caller's row-major tensor.  A full wavefront owns 64
 // consecutive rows, i.e. ONE contiguous block of 64 x NV x sizeof(OutT) bytes (4608 B of float32 observations): the rows go
@@ -536,7 +537,7 @@ struct SbrTraceRec {
     int64_t env;                  // index of the lane's env in the handle
     SBR_DEV void pid(int iv, double e, double ie, double dcv) const {
         if (__builtin_expect(b.trace != nullptr, 0)) {
-            const int64_t steps = (int64_t)((int)(*meta_lds) >> 4);
+            const int64_t steps = (int64_t)((int)(*meta_lds) >> 5);      // meta = steps*32 + idle*16 + status*2 + done
             if (env < b.n_trace && steps < b.trace_cap) {
                 double* rec = b.trace + (steps * SBR_NTRACE) * b.n_trace + env;
                 if (iv == 0) {
@@ -555,9 +556,9 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
     SbrBuf b = b0;
     b.x = bx; b.ctrl = bctrl; b.n = bn;
-    // wave-major: wave w owns park[w][slot][64], 26 (27) slots x 512 B = 13 KiB; the region is reused for the output
-    // transpose (64 float64 observation rows take 9216 B)
-    constexpr int NSLOT = SBR_NPARK + (OCI ? 1 : 0);
+    // wave-major: wave w owns park[w][slot][64], 20 slots x 512 B = 10 KiB; the region is reused for the output
+    // transpose (64 float64 observation rows take 9216 B, float32 observation + state rows together 8448 B)
+    constexpr int NSLOT = SBR_NPARK;
     __shared__ __attribute__((aligned(16))) double park[NSLOT * BLK];
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * BLK;
@@ -580,35 +581,31 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     const double meta0 = CTRL(R_META);
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
-    double ring[SBR_KLA_HIST];
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) ring[j] = CTRL(R_RING0 + j);           // physical slot order
-    const double ret0 = CTRL(R_RET);
+    c.kla_last = CTRL(R_KLA_LAST);
+    const double w8_0 = CTRL(R_W8), ret0 = CTRL(R_RET);
 #if SBR_WARM_MODE == 1
     sbr_warm_kernarg();                       // in the shadow of the global loads above
 #elif SBR_WARM_MODE == 2
     sbr_warm_kernarg_wait(warm_token);
 #endif
-#pragma unroll
-    for (int j = 0; j < SBR_KLA_HIST; ++j) {               // parked in slot order, slots 0..7 twice
-        my[j * 64] = ring[j];
-        if (j < SBR_RING2 - SBR_KLA_HIST) my[(SBR_KLA_HIST + j) * 64] = ring[j];
-    }
-    my[SBR_RING2 * 64] = ret0; my[(SBR_RING2 + 1) * 64] = meta0;
-    // The controller rows are only read inside the `not done` branch below, and the compiler SINKS such a load into the branch:
-    // issued after the batch above has returned, it is a second, fully exposed memory round trip (~0.3 us; seen in the ISA of
-    // rounds 2-3 as one global_load behind the branch).  Passing the values through an empty asm statement here pins their loads
-    // above it, into the one batch.
+    my[SBR_PK_RET * 64] = ret0; my[SBR_PK_META * 64] = meta0; my[SBR_PK_W8 * 64] = w8_0;
+    // The controller rows are only read inside the `not done` branch below, and the compiler SINKS such a load into the branch
+    // (one global_load behind the branch in the ISA of rounds 2-3: the action).  SBR_PIN_LOADS passes the values through an empty
+    // asm statement, which pins their loads into the one batch - measured SLOWER (profiles/r04_notes.md), off by default.
     double a0p = a0, a1p = a1;
 #if SBR_PIN_LOADS
     asm volatile("" : "+v"(c.so_m1), "+v"(c.sno_m1), "+v"(c.ie_do), "+v"(c.ie_ec), "+v"(c.ec_last), "+v"(c.t), "+v"(a0p), "+v"(a1p));
 #endif
-    SbrX6Lds x6{my + (SBR_RING2 + 2) * 64};
-    if (OCI) my[SBR_NPARK * 64] = CTRL(R_KSUM);           // only this reward keeps the running sum of Kla
+    SbrX6Lds x6{my + SBR_PK_X6 * 64};
+    if (OCI) my[SBR_PK_KSUM * 64] = CTRL(R_KSUM);          // only this reward keeps the running sum of Kla
     x6.put(x);
-    const int kb = ring_k(p, c.t) % SBR_KLA_HIST;          // slot of the oldest entry = where the next Kla goes
-    const double* tail0 = my + kb * 64;                    // entry i of the logical tail: tail0[i * 64], i = 0..8
-    c.kla_last = my[ring_wrap(kb + SBR_KLA_HIST - 1) * 64];
+    // the ring slot of the oldest entry = where this call's first Kla goes; the three entries behind it are the ones that leave
+    // the reward's window with this call's appends (SbrHistInc): loads whose address depends on t, issued now, needed after the
+    // integration
+    const int kb = ring_k(p, c.t) % SBR_KLA_HIST;
+    double lv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) lv[j] = CTRL(R_RING0 + ring_wrap(kb + 1 + j));
     const double kla_before = c.kla_last;
     SBR_STAMP(1, true);                       // every load has returned, the parked values are in LDS
     double t_obs = p.t_cycle, r = 0.0;
@@ -620,15 +617,15 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
         SBR_STAMP(2, false);
-        const SbrTraceRec tr{b, my + (SBR_RING2 + 1) * 64, i0 + l};
+        const SbrTraceRec tr{b, my + SBR_PK_META * 64, i0 + l};
 #ifndef SBR_STEP_LOOP
-#define SBR_STEP_LOOP true
+#define SBR_STEP_LOOP false     // straight-line: the second interval of a phase-boundary call out of line (247 VGPRs; the loop form needs 278 with the dependent ring loads live across the integration)
 #endif
         sbr_run_intervals<SBR_STEP_LOOP>(p, c, x, a0p, a1p, x6, tr);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
-        SbrHistLds hs{tail0, kla_before, 0.0, false};
+        SbrHistInc hs{my[SBR_PK_W8 * 64], kla_before, {lv[0], lv[1], lv[2]}, 0.0, false};
         x6.get(xa6);
-        double ksum = OCI ? my[SBR_NPARK * 64] : 0.0;
+        double ksum = OCI ? my[SBR_PK_KSUM * 64] : 0.0;
         r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         if (OCI) CTRL(R_KSUM) = ksum;
@@ -644,24 +641,29 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         store_ctl(b, i0, l, c);
         // the Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally
         // wave-uniform (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the
-        // per-lane form
+        // per-lane form.  A second (phase-boundary call) and a third append (the idle phase of the done call) are rare.
         const int kb_u = __builtin_amdgcn_readfirstlane(kb);
         const bool ring_uniform = __builtin_amdgcn_ballot_w64(kb != kb_u) == 0ull;
-        if (dn && p.terminal) {           // the idle phase appended one more Kla: the logical history moved by n_new + 1
-            double hist[SBR_KLA_HIST];
-            hs.tail(c, hist);
-            store_ring(b, i0, l, kb + c.n_new, hist);   // rare (once per episode): rewrite the whole ring consistently with t
-            CTRL(R_QW) = qw;
-        } else if (ring_uniform) {                  // n_new == 0: no interval ran (t injected as NaN), the list is unchanged
-            if (c.n_new > 0) st_out(&CTRL(R_RING0 + kb_u), c.knew[0]);
-            if (c.n_new > 1) st_out(&CTRL(R_RING0 + ring_wrap(kb_u + 1)), c.knew[1]);
+        const bool idle_pushed = hs.idle_pushed;
+        const double app0 = c.n_new > 0 ? c.knew[0] : hs.idle;            // the appended values in order: knew[0], knew[1], idle
+        const int n_app = c.n_new + (idle_pushed ? 1 : 0);
+        if (ring_uniform) {
+            if (n_app > 0) st_out(&CTRL(R_RING0 + kb_u), app0);
         } else {
-            if (c.n_new > 0) CTRL(R_RING0 + kb) = c.knew[0];
-            if (c.n_new > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = c.knew[1];
+            if (n_app > 0) CTRL(R_RING0 + kb) = app0;
         }
-        meta_unpack(my[(SBR_RING2 + 1) * 64], steps, status, was_done);
-        st_out(&CTRL(R_RET), my[SBR_RING2 * 64] + r);
-        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn));
+        if (__builtin_amdgcn_ballot_w64(n_app > 1) != 0ull) {
+            const double app1 = c.n_new > 1 ? c.knew[1] : hs.idle;
+            if (n_app > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = app1;
+            if (n_app > 2) CTRL(R_RING0 + ring_wrap(kb + 2)) = hs.idle;
+        }
+        double w8_new, last_new;
+        hs.roll(c, w8_new, last_new);
+        st_out(&CTRL(R_KLA_LAST), last_new); st_out(&CTRL(R_W8), w8_new);
+        if (dn && p.terminal) CTRL(R_QW) = qw;
+        meta_unpack(my[SBR_PK_META * 64], steps, status, was_done);
+        st_out(&CTRL(R_RET), my[SBR_PK_RET * 64] + r);
+        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed));
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
             rec[0] = c.t;
@@ -729,11 +731,11 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     SbrRewardParts rp;
     load_x(b, i0, l, x);
     load_ctl_pre(b, i0, l, true, c);
-    load_ring(b, i0, l, ring_k(p, c.t), hist);
+    int steps, status; bool finished, idle_bit;
+    meta_unpack(CTRL(R_META), steps, status, finished, idle_bit);
+    load_ring(b, i0, l, ring_k(p, c.t) + (idle_bit ? 1 : 0), hist);
     c.kla_last = hist[SBR_KLA_HIST - 1];
     double ret = CTRL(R_RET), qw = CTRL(R_QW), ksum = OCI ? CTRL(R_KSUM) : 0.0;
-    int steps, status; bool finished;
-    meta_unpack(CTRL(R_META), steps, status, finished);
     double acc = 0.0;
     bool terminal_due = false;        // the done call happened in this launch: its settle / draw / idle run once, after the loop
     for (int32_t s = 0; s < n_steps; ++s) {
@@ -760,6 +762,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     // the ring is addressed by the interval count recovered from t: store the logical history consistently with the final t
     // (the idle phase's extra Kla does not advance t; k_export reads with the same rule)
     store_ring(b, i0, l, ring_k(p, c.t), hist);
+    CTRL(R_KLA_LAST) = hist[SBR_KLA_HIST - 1]; CTRL(R_W8) = hist_w8(hist);
     CTRL(R_RET) = ret; CTRL(R_META) = meta_pack(steps, status, finished); CTRL(R_QW) = qw;
     if (OCI) CTRL(R_KSUM) = ksum;                     // like k_step: only this reward maintains the row
     if (returns) returns[i] = acc;
@@ -1212,7 +1215,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     CREATE_TRY(hipMemset(e->buf.ctrl, 0, R_NROWS * nb));
     CREATE_TRY(hipMemset(e->buf.infl, 0, SBR_NX * nb));
     // an env is unusable until its first reset: mark everything done so that step() is a no-op until then
-    // (meta = steps*16 + status*2 + done  =>  1.0 = "done"); filled on the device, no host staging buffer
+    // (meta = steps*32 + idle*16 + status*2 + done  =>  1.0 = "done"); filled on the device, no host staging buffer
     hipLaunchKernelGGL(k_fill, grid_for(n_envs), dim3(SBR_BLOCK), 0, nullptr, e->buf.ctrl + (size_t)R_META * n_envs, n_envs, 1.0);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipDeviceSynchronize());

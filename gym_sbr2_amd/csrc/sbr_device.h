@@ -619,32 +619,46 @@ struct SbrHistReg {                       // the fused kernels: ten registers, s
         return s;
     }
 };
-// sum(Kla[-rows:-1]) AFTER this call's n_new appends (module_reward_EQIOCI.py:70), taken from the tail before them: the
-// list then ends ..., old(n_new), ..., old(9), knew[0 .. n_new-1], and the slice is the rows-1 entries before the last one.
-// Left to right like python's sum().
-template <typename H>
-SBR_DEV double sbr_kla_window(const SbrCtl& c, const H& hs) {
-    const bool nine = c.rows >= 10;       // 9 previous values if rows == 10, else 8
-    double s;
-    if (c.n_new == 1) {
-        s = nine ? hs.old(1) : 0.0;
-#pragma unroll
-        for (int i = 2; i <= 9; ++i) s = s + hs.old(i);
-    } else if (c.n_new >= 2) {
-        s = nine ? hs.old(2) : 0.0;
-#pragma unroll
-        for (int i = 3; i <= 9; ++i) s = s + hs.old(i);
-        s = s + c.knew[0];
-    } else {                              // no interval ran (t is NaN or out of range): the list is unchanged
-        s = nine ? hs.old(0) : 0.0;
-#pragma unroll
-        for (int i = 1; i <= 8; ++i) s = s + hs.old(i);
+// k_step's Kla history (round 4): nothing but what a call needs.  The reward sums the 8 or 9 entries before Kla[-1]
+// (module_reward_EQIOCI.py:70, sbr_reward); instead of reading the last ten entries every call, the handle keeps
+//   w8   = the sum of the 8 entries before Kla[-1]          (row R_W8),
+//   last = Kla[-1], the bias of the velocity-form DO-PID     (row R_KLA_LAST),
+// and every append moves the window by one: the entry that leaves it - Kla[-9] for the first append of a call, Kla[-8] and
+// Kla[-7] for a second (phase-boundary call) and a third (the idle phase of the done call) - comes from the 10-slot ring,
+// whose slot depends on the interval count: three loads issued as soon as t has arrived, used seven microseconds later.
+// Per call: 5 rows read instead of 10, no parking of the ring in LDS.  A running sum is not python's left-to-right sum():
+// the two differ by rounding (<= 1e-10 absolute after a whole episode, 3e-16 in the reward); with equal entries (Kla saturated
+// or 0, the common case) every update is exact.
+struct SbrHistInc {
+    double w8, last;
+    double lv[3];
+    double idle;
+    bool idle_pushed;
+    // sum(Kla[-rows:-1]) after this call's n_new appends: rows - 1 = 8 or 9 entries before the new Kla[-1]
+    SBR_DEV double commit_and_window(const SbrCtl& c) const {
+        const bool nine = c.rows >= 10;
+        if (c.n_new <= 0) return w8;                                   // no interval ran (t is NaN): the list is unchanged (rows = 9)
+        const double w1 = w8 + last;                                   // the 9 entries before the first append
+        if (c.n_new == 1) return nine ? w1 : w1 - lv[0];
+        const double w2 = (w1 - lv[0]) + c.knew[0];                    // the 9 entries before the second append
+        return nine ? w2 : w2 - lv[1];
     }
-    return s;
-}
+    SBR_DEV void push(double k) { idle = k; idle_pushed = true; }      // Sim_idle's Kla.append (:2578)
+    // w8 and Kla[-1] as the next call will need them, after all appends of this one
+    SBR_DEV void roll(const SbrCtl& c, double& w8_new, double& last_new) const {
+        double w = w8, prev = last;
+        if (c.n_new > 0) { w = (w - lv[0]) + prev; prev = c.knew[0]; }
+        if (c.n_new > 1) { w = (w - lv[1]) + prev; prev = c.knew[1]; }
+        if (idle_pushed) {                              // (selects, not a dynamic index: that would put lv[] in scratch memory)
+            const double leaving = c.n_new > 1 ? lv[2] : (c.n_new > 0 ? lv[1] : lv[0]);
+            w = (w - leaving) + prev; prev = idle;
+        }
+        w8_new = w; last_new = prev;
+    }
+};
 
 // module_reward_EQIOCI.py:4-115.  Kla got one append per interval, EC got rows-1:  Kla[-rows:-1] is
-// the rows-1 values BEFORE the current one (ksum, see sbr_kla_window), EC[-rows:-1] = last value of the previous interval +
+// the rows-1 values BEFORE the current one (ksum: SbrHistInc / SbrHistReg commit_and_window), EC[-rows:-1] = last value of the previous interval +
 // (rows-2) x current.
 SBR_DEV double sbr_reward(const SbrPar& p, const SbrCtl& c, double ksum, const double (&x)[SBR_NX], SbrRewardParts& rp) {
     const double xi = x[3], xs = x[4], xbh = x[5], xba = x[6], xp = x[7];
