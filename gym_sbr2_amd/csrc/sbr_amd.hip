@@ -628,6 +628,12 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         double ksum = OCI ? my[SBR_PK_KSUM * 64] : 0.0;
         r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
+        // everything that reads the three ring entries loaded before the integration comes BEFORE the first store: the memory
+        // counter retires in order, so a wait for one of those (long finished) loads placed after the plant stores would wait
+        // for the stores' acknowledgements too
+        double w8_new, last_new;
+        hs.roll(c, w8_new, last_new);
+        asm volatile("" : "+v"(w8_new), "+v"(last_new) : : "memory");     // ... and the scheduler is held to that order
         if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
         // (wave-uniform test: no lane of the wave changed them)
@@ -657,8 +663,6 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
             if (n_app > 1) CTRL(R_RING0 + ring_wrap(kb + 1)) = app1;
             if (n_app > 2) CTRL(R_RING0 + ring_wrap(kb + 2)) = hs.idle;
         }
-        double w8_new, last_new;
-        hs.roll(c, w8_new, last_new);
         st_out(&CTRL(R_KLA_LAST), last_new); st_out(&CTRL(R_W8), w8_new);
         if (dn && p.terminal) CTRL(R_QW) = qw;
         meta_unpack(my[SBR_PK_META * 64], steps, status, was_done);
