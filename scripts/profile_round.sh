@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profiling recipe of a round, to be run ON THE GPU BOX (inside one gpurun call):
-#   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh r03'        then here:  cp gpurun_out/r03/profiles/* profiles/
+#   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh r04'        then here:  cp gpurun_out/r04/profiles/* profiles/ &&
+#   python scripts/design_glance.py r04 --write   (DESIGN.md's table and README's headline are generated from these files)
 # Writes everything under gpurun_out/<tag>/; scripts/pmc_summarise.py (run on the box, it needs no GPU) distils the passes
 # into profiles/<tag>_*, and the bench lines are taken LAST, so that their roofline.traffic can quote the PMC summary of this
 # very library (bench.py matches it by source hash).  Separate passes on purpose: --kernel-trace --stats for durations; one
@@ -30,5 +31,7 @@ done
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_config2_driver_style.json 2> $out/bench_driver.err
 cp $out/bench_config2_driver_style.json profiles/${tag}_bench_config2_driver_style.json
 echo "bench driver-style: $(cut -c1-160 $out/bench_config2_driver_style.json)"
+timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -2 > profiles/${tag}_pytest_gpu.log || true
+echo "gpu tests: $(tail -1 profiles/${tag}_pytest_gpu.log)"
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/
 echo "profile_round $tag finished"

@@ -46,3 +46,38 @@ def test_committed_profile_matches_the_sources_or_says_so():
         warnings.warn("profiles/ holds no PMC profile of the current kernel sources: " + why)
     else:
         assert rec["hbm_bytes_per_launch"] > 0 and os.path.exists(os.path.join(ROOT, rec["_file"]))
+
+
+def test_design_glance_table_is_generated_from_the_committed_profiles():
+    """round 3's DESIGN quoted 1.36 B per env-step for the fused rollout where the committed JSON held 3.51.
+    The "at a glance" table of DESIGN.md section 5 is now generated from the committed profile files
+    (scripts/design_glance.py); regenerating it must give exactly the text DESIGN.md holds."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("design_glance", os.path.join(ROOT, "scripts", "design_glance.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    tag = "r04"
+    begin = g.BEGIN % tag
+    assert begin in text and g.END in text
+    held = text[text.index(begin) + len(begin):text.index(g.END, text.index(begin))].strip()
+    assert held == g.table(tag).strip()
+    # README.md leads with figures of the same files: its first bullet is generated too
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    hb = g.HL_BEGIN % tag
+    assert hb in readme and g.HL_END in readme
+    assert readme[readme.index(hb) + len(hb):readme.index(g.HL_END, readme.index(hb))].strip() == g.headline(tag).strip()
+    # and the prose quotes the fused rollout's traffic as the JSON holds it (the figure round 3 got wrong)
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)))
+    assert ("%.2f B per env-step" % pmc["rollout"]["hbm_bytes_per_env_step"]) in text
+
+
+def test_reference_cpu_timing_file_is_what_bench_reports():
+    """cpu_baseline.reference is read from profiles/reference_cpu_timing.json, written by oracle/time_reference.py in the build
+    container (the reference cannot travel): no constant pasted into bench.py."""
+    rec = bench.reference_cpu()
+    raw = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json")))
+    assert rec["value"] == raw["value"] and rec["cores"] == 1 and rec["value_all_cores"] == raw["value_all_cores"]
+    assert 500 < rec["value"] < 1e4 and rec["script"] == "oracle/time_reference.py" and "NOT the GPU box" in rec["hardware"]
+    assert abs(raw["one_process"]["episode_return_seed0"] - -0.8789670883455737) < 1e-12       # the reference's anchor, reproduced
+    assert "REFERENCE_CPU" not in open(os.path.join(ROOT, "bench.py")).read()

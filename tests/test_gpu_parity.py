@@ -344,9 +344,10 @@ def test_config2_4096_envs_full_episode_against_oracle(G, tables):
 
 
 def test_two_waves_per_simd_kernel_build_matches_oracle(G, tables):
-    """Batches above 98304 envs are stepped by the second build of k_step (two waves resident per SIMD).  Lockstep
-    check of that build: 98368 envs, the oracle follows a 512-env sample (first, middle and last waves) for 60 calls,
-    crossing the anoxic -> aerobic boundary (one double step)."""
+    """Batches above SBR_SMALL_BATCH = 49152 envs run the 256-thread-workgroup instantiation of k_step (one source, two
+    workgroup sizes), and from 65536 envs up more than one wave is resident per SIMD.  Lockstep check of that regime: 98368
+    envs (not a multiple of 256: the last workgroup is ragged), the oracle follows a 512-env sample (first, middle and last
+    waves) for 60 calls, crossing the anoxic -> aerobic boundary (one double step)."""
     from gym_sbr2_amd import _capi
     means, stds = tables
     n, calls = 98304 + 64, 60
