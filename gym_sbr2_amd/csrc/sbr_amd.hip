@@ -44,17 +44,17 @@ struct SbrBuf {
     int64_t n;
     int64_t first_env_id;
 #ifdef SBR_STAMPS
-    unsigned long long* stamps;   // diagnostic build only (scripts/probes/step_timeline.py): [waves][8] s_memrealtime ticks
+    unsigned long long* stamps;   // diagnostic build only (scripts/probes/step_timeline.py): [waves][16] s_memrealtime ticks
 #endif
 };
-// Diagnostic build -DSBR_STAMPS: lane 0 of every wave records the 100 MHz real-time counter at eight points of k_step.
+// Diagnostic build -DSBR_STAMPS: lane 0 of every wave records the 100 MHz real-time counter at up to sixteen points of k_step.
 // The stamps go to a buffer of their own that nothing else reads; the product build contains none of this.
 #ifdef SBR_STAMPS
 #define SBR_STAMP(k, drain)                                                                                   \
     do {                                                                                                      \
         if (drain) __builtin_amdgcn_s_waitcnt(0);                                                             \
         if (b.stamps != nullptr && (l & 63u) == 0u)                                                           \
-            b.stamps[(uint64_t)((i0 + l) >> 6) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                \
+            b.stamps[(uint64_t)((i0 + l) >> 6) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();               \
     } while (0)
 #else
 #define SBR_STAMP(k, drain) do { } while (0)
@@ -634,6 +634,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         double w8_new, last_new;
         hs.roll(c, w8_new, last_new);
         asm volatile("" : "+v"(w8_new), "+v"(last_new) : : "memory");     // ... and the scheduler is held to that order
+        SBR_STAMP(8, false);                  // window rolled: everything that waits for a load is done
         if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
         // (wave-uniform test: no lane of the wave changed them)
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 #pragma unroll
             for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) st_out(&XROW(j), x[j]);
         }
+        SBR_STAMP(9, false);                  // plant stores issued
         store_ctl(b, i0, l, c);
         // the Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally
         // wave-uniform (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         meta_unpack(my[SBR_PK_META * 64], steps, status, was_done);
         st_out(&CTRL(R_RET), my[SBR_PK_RET * 64] + r);
         st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed));
+        SBR_STAMP(10, false);                 // controller stores issued
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
             rec[0] = c.t;
@@ -691,6 +694,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     SBR_STAMP(5, false);                      // state stores issued
     if (reward) st_out(&(reward + i0)[l], (OutT)r);
     if (done) st_out(&(done + i0)[l], (uint8_t)(dn ? 1 : 0));
+    SBR_STAMP(11, false);                     // reward / done stores issued
     const bool wide = __builtin_amdgcn_ballot_w64(true) == ~0ull;      // all 64 lanes of the wave hold an env
     char* stage = reinterpret_cast<char*>(wave_lds);
     // both row sets fit the wave's staging region together when they are float32 (64 x (72 + 60) = 8448 of 13312 bytes)
@@ -699,6 +703,10 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         OutT o[SBR_NOBS], sv[SBR_NSTATE];
         sbr_write_obs<OutT>(o, 1, t_obs, x, xa6, x);
         sbr_write_state<OutT>(sv, 1, t_obs, x);
+#ifdef SBR_STAMPS
+        asm volatile("" : "+v"(o[0]), "+v"(o[17]), "+v"(sv[14]) : : "memory");
+#endif
+        SBR_STAMP(12, false);                 // output values formed
         store_rows2<OutT, SBR_NOBS, SBR_NSTATE>(obs + i0 * SBR_NOBS, state + i0 * SBR_NSTATE, l, stage, wide, o, sv);
     } else {
         if (obs) {

@@ -28,7 +28,7 @@ for N in sizes:
     if os.environ.get("SBR_TL_POLICY") == "dose":      # NO3 set-point 0: every lane doses carbon in the anoxic phases
         a[:, 1] = 0.0
     waves = (N + 63) // 64
-    buf = torch.zeros(waves, 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(waves, 16, dtype=torch.int64, device="cuda")
     for phase_calls, label in ((20, "anoxic (dosing code path)"), (120, "aerobic (no dosing)")):
         env.reset(seed=1, scenario=scen)
         for _ in range(3):                      # steady clocks
@@ -49,9 +49,11 @@ for N in sizes:
         t0 = t[:, 0].min()
         rel = (t - t0) * 0.01                   # 100 MHz ticks -> us
         print("N = %d, %s: offsets from the first wave's entry, us (min / median / max over %d waves)" % (N, label, waves))
-        for k, name in enumerate(["entry", "loads returned", "before intervals", "RK4 done", "reward done", "state stores issued",
-                                  "output stores issued", "stores acknowledged"]):
-            print("   %d %-22s %7.2f %7.2f %7.2f" % (k, name, rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
-        d = np.diff(rel, axis=1)
-        print("   per-wave segment medians: " + "  ".join("%d->%d %.2f" % (k, k + 1, np.median(d[:, k])) for k in range(7)))
+        names = {0: "entry", 1: "loads returned", 2: "before intervals", 3: "RK4 done", 4: "reward done", 8: "window rolled",
+                 9: "plant stores issued", 10: "controller stores issued", 5: "state stores issued (+trace)", 11: "reward/done stores issued",
+                 12: "output values formed", 6: "output stores issued", 7: "stores acknowledged"}
+        order = [k for k in (0, 1, 2, 3, 4, 8, 9, 10, 5, 11, 12, 6, 7) if t[:, k].max() > 0]
+        for k in order:
+            print("   %2d %-30s %7.2f %7.2f %7.2f" % (k, names[k], rel[:, k].min(), np.median(rel[:, k]), rel[:, k].max()))
+        print("   per-wave segment medians: " + "  ".join("%d->%d %.2f" % (a, b_, np.median(rel[:, b_] - rel[:, a])) for a, b_ in zip(order[:-1], order[1:])))
     env.close()
