@@ -505,6 +505,11 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
         "s_load_dword %0, %1, 0x340\n s_load_dword %0, %1, 0x380\n s_load_dword %0, %1, 0x3c0\n s_load_dword %0, %1, 0x400\n"     \
         "s_load_dword %0, %1, 0x440\n s_load_dword %0, %1, 0x480\n s_load_dword %0, %1, 0x4c0\n s_load_dword %0, %1, 0x500\n"     \
         "s_load_dword %0, %1, 0x538\n"
+// k_step's argument segment: four pointers / sizes, the flags word (+ padding), four pointers, SbrPar, SbrBuf.  The touched
+// offsets must stay inside it (a scalar load past the segment may fault) and reach its last line.
+static constexpr size_t kStepKernargBytes = 72 + sizeof(SbrPar) + sizeof(SbrBuf);
+static_assert(kStepKernargBytes >= 0x538 + 4 && kStepKernargBytes <= 0x538 + 64,
+              "SbrPar / SbrBuf changed size: adjust the offsets of SBR_WARM_LINES to cover k_step's argument segment");
 SBR_DEV void sbr_warm_kernarg() {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     uint32_t t;
