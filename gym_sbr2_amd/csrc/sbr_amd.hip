@@ -488,15 +488,11 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
 // segment of a launch is a fresh buffer in device memory that no cache has seen: the first touch of each of its 64-byte lines
 // is a miss in the scalar cache that goes out to L2 / memory, and every such piece sits behind its own s_waitcnt ON the
 // wave's critical path (PMC, round 4: SQ_WAIT_ANY is what grew when an unrelated code change added two late scalar loads,
-// +0.3 us per launch).  So every line of the segment is touched ONCE, all at the same time, right after the wave's global
-// loads have been issued: the misses overlap each other and the ~2 us of global-load latency, and every later scalar load
-// of a constant hits the scalar cache.  The loads target one scratch SGPR whose value is never used; the s_waitcnt inside
-// the statement makes sure none of them is still in flight when the compiler reuses that register.
-#ifndef SBR_WARM_MODE
-#define SBR_WARM_MODE 2        // 0 off, 1 one statement after the global loads, 2 issued at wave start and awaited after the global loads (measured best: profiles/r04_notes.md)
-#endif
-#ifndef SBR_PIN_LOADS
-#define SBR_PIN_LOADS 0
+// +0.3 us per launch).  So every line of the segment is touched ONCE, all at the same time, at wave start: the misses
+// overlap each other and the ~2 us of global-load latency, and every later scalar load of a constant hits the scalar cache.
+// The loads target one scratch SGPR whose value is never used.
+#ifndef SBR_KERNARG_WARM
+#define SBR_KERNARG_WARM 1     // 0 switches the warm-up off (A/B builds only; measured: profiles/r04_ab_kernarg_warm_modes.log)
 #endif
 #define SBR_WARM_LINES                                                                                                            \
         "s_load_dword %0, %1, 0x40\n s_load_dword %0, %1, 0x80\n s_load_dword %0, %1, 0xc0\n s_load_dword %0, %1, 0x100\n"        \
@@ -510,14 +506,9 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
 static constexpr size_t kStepKernargBytes = 72 + sizeof(SbrPar) + sizeof(SbrBuf);
 static_assert(kStepKernargBytes >= 0x538 + 4 && kStepKernargBytes <= 0x538 + 64,
               "SbrPar / SbrBuf changed size: adjust the offsets of SBR_WARM_LINES to cover k_step's argument segment");
-SBR_DEV void sbr_warm_kernarg() {
-    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t t;
-    asm volatile(SBR_WARM_LINES "s_waitcnt lgkmcnt(0)" : "=&s"(t) : "s"(kp) : "memory");
-    (void)t;
-}
-// the same in two halves: the scratch register stays allocated (an in/out operand of the second statement) until the loads
-// have landed, so the compiler cannot hand it to anything else while they are in flight
+// In two halves, issue at wave start and wait after the wave's global loads have gone out: the scratch register stays allocated
+// (an in/out operand of the second statement) until the loads have landed, so the compiler cannot hand it to anything else
+// while they are in flight.  (One statement placed after the global loads was measured too: +0.2 us per launch.)
 SBR_DEV uint32_t sbr_warm_kernarg_issue() {
     auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     uint32_t t;
@@ -576,7 +567,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     double x[SBR_NX];
     SbrCtl c;
     SBR_STAMP(0, false);
-#if SBR_WARM_MODE == 2
+#if SBR_KERNARG_WARM
     const uint32_t warm_token = sbr_warm_kernarg_issue();
 #endif
     // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
@@ -588,19 +579,12 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
     c.kla_last = CTRL(R_KLA_LAST);
     const double w8_0 = CTRL(R_W8), ret0 = CTRL(R_RET);
-#if SBR_WARM_MODE == 1
-    sbr_warm_kernarg();                       // in the shadow of the global loads above
-#elif SBR_WARM_MODE == 2
+#if SBR_KERNARG_WARM
     sbr_warm_kernarg_wait(warm_token);
 #endif
     my[SBR_PK_RET * 64] = ret0; my[SBR_PK_META * 64] = meta0; my[SBR_PK_W8 * 64] = w8_0;
-    // The controller rows are only read inside the `not done` branch below, and the compiler SINKS such a load into the branch
-    // (one global_load behind the branch in the ISA of rounds 2-3: the action).  SBR_PIN_LOADS passes the values through an empty
-    // asm statement, which pins their loads into the one batch - measured SLOWER (profiles/r04_notes.md), off by default.
-    double a0p = a0, a1p = a1;
-#if SBR_PIN_LOADS
-    asm volatile("" : "+v"(c.so_m1), "+v"(c.sno_m1), "+v"(c.ie_do), "+v"(c.ie_ec), "+v"(c.ec_last), "+v"(c.t), "+v"(a0p), "+v"(a1p));
-#endif
+    // (The compiler sinks the action load into the `not done` branch below - one global_load behind the branch in the ISA.
+    // Pinning it into the batch above was measured SLOWER, profiles/r04_ab_kernarg_warm_and_pinned_loads.log: left alone.)
     SbrX6Lds x6{my + SBR_PK_X6 * 64};
     if (OCI) my[SBR_PK_KSUM * 64] = CTRL(R_KSUM);          // only this reward keeps the running sum of Kla
     x6.put(x);
@@ -626,7 +610,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 #ifndef SBR_STEP_LOOP
 #define SBR_STEP_LOOP false     // straight-line: the second interval of a phase-boundary call out of line (247 VGPRs; the loop form needs 278 with the dependent ring loads live across the integration)
 #endif
-        sbr_run_intervals<SBR_STEP_LOOP>(p, c, x, a0p, a1p, x6, tr);
+        sbr_run_intervals<SBR_STEP_LOOP>(p, c, x, a0, a1, x6, tr);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
         SbrHistInc hs{my[SBR_PK_W8 * 64], kla_before, {lv[0], lv[1], lv[2]}, 0.0, false};
         x6.get(xa6);
