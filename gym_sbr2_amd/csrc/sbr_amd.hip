@@ -524,6 +524,16 @@ SBR_DEV void sbr_warm_kernarg_wait(uint32_t t) { asm volatile("s_waitcnt lgkmcnt
 // or a trace buffer), taken on the host: until round 4 that test read two fields of `p` and one of `b0`, and the s_waitcnt
 // in front of it held back EVERY global load of the wave for a scalar round trip to the argument segment.
 #define SBR_KF_NEED_M2 1u
+#define SBR_KF_STAGGER 2u
+#ifndef SBR_STAGGER_SLEEP
+#define SBR_STAGGER_SLEEP 25        // x 64 cycles
+#endif
+#ifndef SBR_STAGGER_MIN_ENVS
+#define SBR_STAGGER_MIN_ENVS 0      // every launch in 256-thread workgroups (> SBR_SMALL_BATCH envs); A/B builds move the window
+#endif
+#ifndef SBR_STAGGER_MAX_ENVS
+#define SBR_STAGGER_MAX_ENVS (1ll << 62)
+#endif
 // trajectory export: the NO3-PID's e / ie / dcv of every interval go straight to the call's trace record while the PID runs
 // (slot _FIRST for the first interval of the call, the plain slots for the last one run), so that nothing has to be carried
 // across the integration for it.  Off (b.trace == NULL, the default) this is one untaken scalar branch per interval.
@@ -570,6 +580,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 #if SBR_KERNARG_WARM
     const uint32_t warm_token = sbr_warm_kernarg_issue();
 #endif
+    // Staggered entry (SBR_KF_STAGGER, large batches): every other workgroup of an XCD (workgroup g runs on XCD g % 8, so bit 3
+    // of the index alternates inside one) waits ~0.65 us before its loads.  With one wave per SIMD every wave of the chip
+    // otherwise loads at the same moment and stores at the same moment; half a microsecond of skew inside each XCD takes the
+    // two bursts apart (measured: profiles/r04_notes.md, "staggered entry").
+    if ((flags & SBR_KF_STAGGER) != 0u && ((blockIdx.x >> 3) & 1u) != 0u) __builtin_amdgcn_s_sleep(SBR_STAGGER_SLEEP);
     // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
     // in logical order, whose rows depend on t: a second, dependent round trip)
     load_x(b, i0, l, x);
@@ -1092,8 +1107,9 @@ static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state
                            e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
         hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
-                           e->buf.ctrl, e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par,
-                           e->buf);
+                           e->buf.ctrl, e->buf.n, (const ActT*)action,
+                           flags | ((e->n >= SBR_STAGGER_MIN_ENVS && e->n <= SBR_STAGGER_MAX_ENVS) ? SBR_KF_STAGGER : 0u), (OutT*)obs,
+                           (OutT*)state, (OutT*)reward, done, e->par, e->buf);
 }
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
