@@ -119,16 +119,21 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[
 //    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten, and
 //    (round 4) READS three: next to the ring the handle keeps Kla[-1] and the sum of the eight entries before it, from which
 //    the reward's window follows incrementally (SbrHistInc in sbr_device.h);
-//  * steps, the idle-append flag, status bits and the done flag share one row (meta = steps*32 + idle*16 + status*2 + done,
-//    an integer < 2^31 held in a double: steps saturate at 2^26 - 1 calls per episode);
+//  * steps, two flags, status bits and the done flag share one row (meta = steps*64 + m1i*32 + idle*16 + status*2 + done,
+//    an integer < 2^31 held in a double: steps saturate at 2^25 - 1 calls per episode);
+//  * So[-1] and Sno[-1] are IMPLICIT after an ordinary step (round 4): every interval ends with So.append(x_out[-1][8]),
+//    Sno.append(x_out[-1][9]) (:1955-1956, :2043-2044), so after a step the two values ARE x[8] and x[9] and k_step neither
+//    stores nor loads their rows (meta's m1i bit says so).  Whoever writes values that are NOT the plant's - the reset (Ss in
+//    the Sno memory, :1652), an import, a rollout, the done call (the terminal phases move x afterwards) - stores the rows and
+//    leaves the bit clear; the next step then fetches them in a second, dependent load (once per episode);
 //  * rows only read when tauD != 0 (So[-2], Sno[-2]), only at the end of an episode (Qw) or only by the operating-cost
 //    reward (the running sum of Kla) come last.
-// Per env-step the step kernel reads 13 controller rows (t, So[-1], Sno[-1], two integrals, EC[-1], return, meta, Kla[-1], w8,
-// three ring slots) and writes 13 (those minus the three slots, plus So[-2], Sno[-2] and one ring slot): 208 B, where the
-// public layout would take 20 + 24 rows (352 B) and rounds 2-3 took 18 + 11 (232 B).
+// Per env-step the step kernel reads 11 controller rows (t, two integrals, EC[-1], return, meta, Kla[-1], w8, three ring
+// slots) and writes 11 (those minus the three slots, plus So[-2], Sno[-2] and one ring slot): 176 B, where the public layout
+// would take 20 + 24 rows (352 B) and rounds 2-3 took 18 + 11 (232 B).
 enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_KLA_LAST, R_W8, R_RING0,
        R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_KSUM, R_NROWS };
-#define SBR_MAX_STEPS ((1 << 26) - 1)
+#define SBR_MAX_STEPS ((1 << 25) - 1)
 
 SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since reset, from the running time
     double q = __builtin_fma(t - p.T_fill, p.inv_t_delta, 0.5);
@@ -137,16 +142,20 @@ SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since r
     return (int)q;
 }
 SBR_DEV int ring_wrap(int s) { return s >= SBR_KLA_HIST ? s - SBR_KLA_HIST : s; }       // for 0 <= s < 20
-// meta = steps*32 + idle*16 + status*2 + done.  `idle`: the done call of k_step appended one more Kla than t accounts for
-// (Sim_idle's, :2578): the ring's oldest entry then sits one slot further than ring_k(t) says (k_export adds it; a reset, an
-// import or a rollout store the ring in plain order and clear the bit).
-SBR_DEV double meta_pack(int steps, int status, bool done, bool idle = false) {
-    return (double)(steps * 32 + (idle ? 16 : 0) + status * 2 + (done ? 1 : 0));
+// meta = steps*64 + m1i*32 + idle*16 + status*2 + done.  `idle`: the done call of k_step appended one more Kla than t accounts
+// for (Sim_idle's, :2578): the ring's oldest entry then sits one slot further than ring_k(t) says (k_export adds it; a reset,
+// an import or a rollout store the ring in plain order and clear the bit).  `m1i`: So[-1], Sno[-1] are x[8], x[9], their rows
+// are stale (set by an ordinary k_step call only; every other writer stores the rows and leaves it clear).
+#define SBR_META_M1I 32
+#define SBR_META_STEPS_SHIFT 6
+SBR_DEV double meta_pack(int steps, int status, bool done, bool idle = false, bool m1i = false) {
+    return (double)((steps << SBR_META_STEPS_SHIFT) + (m1i ? SBR_META_M1I : 0) + (idle ? 16 : 0) + status * 2 + (done ? 1 : 0));
 }
-SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done, bool& idle) {
+SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done, bool& idle, bool& m1i) {
     const int v = (int)m;
-    done = (v & 1) != 0; status = (v >> 1) & 7; idle = (v & 16) != 0; steps = v >> 5;
+    done = (v & 1) != 0; status = (v >> 1) & 7; idle = (v & 16) != 0; m1i = (v & SBR_META_M1I) != 0; steps = v >> SBR_META_STEPS_SHIFT;
 }
+SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done, bool& idle) { bool m1i; meta_unpack(m, steps, status, done, idle, m1i); }
 SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done) { bool idle; meta_unpack(m, steps, status, done, idle); }
 // the two rows k_step keeps next to the ring (SbrHistInc), from a history in logical order (oldest first, hist[9] = Kla[-1])
 SBR_DEV double hist_w8(const double (&hist)[SBR_KLA_HIST]) {
@@ -158,18 +167,22 @@ SBR_DEV double hist_w8(const double (&hist)[SBR_KLA_HIST]) {
 
 // Rows the step consumes BEFORE the integration.  So[-2], Sno[-2] only feed the derivative term (tauD != 0) and the
 // trajectory export's dcv_EC: read only then (need_m2, wave-uniform).
-SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2, SbrCtl& c) {
-    c.t = CTRL(R_T); c.so_m1 = CTRL(R_SO_M1); c.sno_m1 = CTRL(R_SNO_M1);
+// (k_step reads So[-1] / Sno[-1] from the plant when meta says they are implicit; here: the general form, m1i from meta)
+SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2, bool m1i, const double (&x)[SBR_NX], SbrCtl& c) {
+    c.t = CTRL(R_T);
+    c.so_m1 = x[8]; c.sno_m1 = x[9];
+    if (!m1i) { c.so_m1 = CTRL(R_SO_M1); c.sno_m1 = CTRL(R_SNO_M1); }
     c.ie_do = CTRL(R_IE_DO); c.ie_ec = CTRL(R_IE_EC); c.ec_last = CTRL(R_EC_LAST);
     c.so_m2 = need_m2 ? CTRL(R_SO_M2) : c.so_m1;
     c.sno_m2 = need_m2 ? CTRL(R_SNO_M2) : c.sno_m1;
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
     c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
 }
-// rows every step rewrites (the ring slot(s), return and meta are written by the caller)
-SBR_DEV void store_ctl(const SbrBuf& b, int64_t i0, uint32_t l, const SbrCtl& c) {
-    st_out(&CTRL(R_T), c.t); st_out(&CTRL(R_SO_M1), c.so_m1); st_out(&CTRL(R_SO_M2), c.so_m2);
-    st_out(&CTRL(R_SNO_M1), c.sno_m1); st_out(&CTRL(R_SNO_M2), c.sno_m2);
+// rows every step rewrites (the ring slot(s), return and meta are written by the caller); with_m1 = false leaves So[-1] and
+// Sno[-1] implicit (the caller then sets meta's m1i bit)
+SBR_DEV void store_ctl(const SbrBuf& b, int64_t i0, uint32_t l, const SbrCtl& c, bool with_m1 = true) {
+    st_out(&CTRL(R_T), c.t); st_out(&CTRL(R_SO_M2), c.so_m2); st_out(&CTRL(R_SNO_M2), c.sno_m2);
+    if (with_m1) { st_out(&CTRL(R_SO_M1), c.so_m1); st_out(&CTRL(R_SNO_M1), c.sno_m1); }
     st_out(&CTRL(R_IE_DO), c.ie_do); st_out(&CTRL(R_IE_EC), c.ie_ec); st_out(&CTRL(R_EC_LAST), c.ec_last);
 }
 // whole history, logical order (oldest first), for the given interval count (per-lane slot: the general, slower form)
@@ -190,12 +203,12 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
     if (i >= b.n) return;
     double v[SBR_NCTRL], hist[SBR_KLA_HIST];
-    int steps, status; bool done, idle;
+    int steps, status; bool done, idle, m1i;
     const double t = CTRL(R_T);
-    meta_unpack(CTRL(R_META), steps, status, done, idle);
+    meta_unpack(CTRL(R_META), steps, status, done, idle, m1i);
     load_ring(b, i0, l, ring_k(p, t) + (idle ? 1 : 0), hist);
-    v[SBR_C_T] = t; v[SBR_C_SO_M1] = CTRL(R_SO_M1); v[SBR_C_SO_M2] = CTRL(R_SO_M2);
-    v[SBR_C_SNO_M1] = CTRL(R_SNO_M1); v[SBR_C_SNO_M2] = CTRL(R_SNO_M2);
+    v[SBR_C_T] = t; v[SBR_C_SO_M1] = m1i ? XROW(8) : CTRL(R_SO_M1); v[SBR_C_SO_M2] = CTRL(R_SO_M2);
+    v[SBR_C_SNO_M1] = m1i ? XROW(9) : CTRL(R_SNO_M1); v[SBR_C_SNO_M2] = CTRL(R_SNO_M2);
     v[SBR_C_IE_DO] = CTRL(R_IE_DO); v[SBR_C_IE_EC] = CTRL(R_IE_EC); v[SBR_C_EC_LAST] = CTRL(R_EC_LAST);
 #pragma unroll
     for (int j = 0; j < SBR_KLA_HIST; ++j) v[SBR_C_KLA_HIST0 + j] = hist[j];
@@ -543,7 +556,7 @@ struct SbrTraceRec {
     int64_t env;                  // index of the lane's env in the handle
     SBR_DEV void pid(int iv, double e, double ie, double dcv) const {
         if (__builtin_expect(b.trace != nullptr, 0)) {
-            const int64_t steps = (int64_t)((int)(*meta_lds) >> 5);      // meta = steps*32 + idle*16 + status*2 + done
+            const int64_t steps = (int64_t)((int)(*meta_lds) >> SBR_META_STEPS_SHIFT);      // meta = steps*64 + flags
             if (env < b.n_trace && steps < b.trace_cap) {
                 double* rec = b.trace + (steps * SBR_NTRACE) * b.n_trace + env;
                 if (iv == 0) {
@@ -588,8 +601,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
     // every load below has an address that depends on nothing loaded: ONE memory round trip (the ring used to be read
     // in logical order, whose rows depend on t: a second, dependent round trip)
     load_x(b, i0, l, x);
-    load_ctl_pre(b, i0, l, (flags & SBR_KF_NEED_M2) != 0u, c);
     const double meta0 = CTRL(R_META);
+    c.t = CTRL(R_T); c.ie_do = CTRL(R_IE_DO); c.ie_ec = CTRL(R_IE_EC); c.ec_last = CTRL(R_EC_LAST);
+    c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
+    if ((flags & SBR_KF_NEED_M2) != 0u) { c.so_m2 = CTRL(R_SO_M2); c.sno_m2 = CTRL(R_SNO_M2); }
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
     c.kla_last = CTRL(R_KLA_LAST);
@@ -620,6 +636,14 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         int steps, status; bool was_done;
         SbrRewardParts rp;
         const double v0 = x[0], si0 = x[1], xi0 = x[3];
+        // So[-1], Sno[-1]: the plant's own values after an ordinary step (meta's m1i bit); the first call after a reset, an import
+        // or a rollout fetches the rows (a second, dependent load: once per episode)
+        c.so_m1 = x[8]; c.sno_m1 = x[9];
+        const bool m1_rows = ((int)meta0 & SBR_META_M1I) == 0;
+        if (__builtin_amdgcn_ballot_w64(m1_rows) != 0ull) {
+            if (m1_rows) { c.so_m1 = CTRL(R_SO_M1); c.sno_m1 = CTRL(R_SNO_M1); }
+        }
+        if ((flags & SBR_KF_NEED_M2) == 0u) { c.so_m2 = c.so_m1; c.sno_m2 = c.sno_m1; }
         SBR_STAMP(2, false);
         const SbrTraceRec tr{b, my + SBR_PK_META * 64, i0 + l};
 #ifndef SBR_STEP_LOOP
@@ -650,7 +674,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
             for (int j = 0; j < SBR_NX; ++j) if (j != 0 && j != 1 && j != 3) st_out(&XROW(j), x[j]);
         }
         SBR_STAMP(9, false);                  // plant stores issued
-        store_ctl(b, i0, l, c);
+        // So[-1], Sno[-1] stay implicit unless this was the done call (the terminal phases have moved x away from them)
+        store_ctl(b, i0, l, c, false);
+        if (__builtin_amdgcn_ballot_w64(dn) != 0ull) {
+            if (dn) { CTRL(R_SO_M1) = c.so_m1; CTRL(R_SNO_M1) = c.sno_m1; }
+        }
         // the Kla ring is addressed by the interval count: envs reset together share it, so the slot is normally
         // wave-uniform (scalar row arithmetic); a wave whose lanes disagree (masked resets, injected states) takes the
         // per-lane form.  A second (phase-boundary call) and a third append (the idle phase of the done call) are rare.
@@ -673,7 +701,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
         if (dn && p.terminal) CTRL(R_QW) = qw;
         meta_unpack(my[SBR_PK_META * 64], steps, status, was_done);
         st_out(&CTRL(R_RET), my[SBR_PK_RET * 64] + r);
-        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed));
+        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed, !dn));
         SBR_STAMP(10, false);                 // controller stores issued
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
@@ -746,9 +774,9 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, in
     SbrX6Reg x6;
     SbrRewardParts rp;
     load_x(b, i0, l, x);
-    load_ctl_pre(b, i0, l, true, c);
-    int steps, status; bool finished, idle_bit;
-    meta_unpack(CTRL(R_META), steps, status, finished, idle_bit);
+    int steps, status; bool finished, idle_bit, m1i;
+    meta_unpack(CTRL(R_META), steps, status, finished, idle_bit, m1i);
+    load_ctl_pre(b, i0, l, true, m1i, x, c);
     load_ring(b, i0, l, ring_k(p, c.t) + (idle_bit ? 1 : 0), hist);
     c.kla_last = hist[SBR_KLA_HIST - 1];
     double ret = CTRL(R_RET), qw = CTRL(R_QW), ksum = OCI ? CTRL(R_KSUM) : 0.0;

@@ -1738,3 +1738,67 @@ def test_configs3_shard_of_a_fused_rollout_equals_the_slice_of_the_262144_env_ro
     assert torch.equal(r_sh, r_big[first:first + n]) and torch.equal(x_sh, x_big[:, first:first + n]) and torch.equal(c_sh, c_big[:, first:first + n])
     assert bool((c_big[_capi.C_DONE] == 1).all()) and bool(torch.isfinite(r_big).all())
     sh.close(); big.close()
+
+
+@pytest.mark.gpu
+def test_implicit_so_sno_memories_across_every_writer(G, tables):
+    """Round 4: after an ordinary step So[-1] / Sno[-1] ARE x[8] / x[9] (every interval ends with So.append(x_out[-1][8]),
+    Sno.append(x_out[-1][9]), gym_SBR_oneshot.py:1955-1956, :2043-2044), and k_step neither stores nor loads their rows.  The
+    public rows must still read as the reference's lists would, whoever wrote last: the reset (Ss in the Sno memory, :1652),
+    an import of values that are NOT the plant's, a fused rollout in between, the done call."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 192
+    scen = (np.arange(n) % 8).astype(np.int32)
+    z = np.random.RandomState(5).randn(n, 48)
+    rs = np.random.RandomState(6)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    env.reset(scenario=scen, rnd=z)
+    x, ctrl = env.get_state()
+    assert torch.equal(ctrl[_capi.C_SNO_M1], x[2]) and torch.equal(ctrl[_capi.C_SO_M1], x[8])          # the reset's quirk
+    ora = O.OracleBatch(n, nthreads=8)
+    ora.reset(ora.mix(means, stds, scen, z))
+
+    def lockstep(calls):
+        for _ in range(calls):
+            a = np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)])
+            xx, cc = env.get_state()
+            ora.load_state(_np(xx), _np(cc))
+            _, _, r, d = env.step(torch.from_numpy(a).cuda())
+            _, _, orr, od = ora.step(a)
+            xx, cc = env.get_state()
+            cc = _np(cc)
+            assert np.abs(_np(r) - orr).max() < 1e-11 and np.array_equal(_np(d), od)
+            for row, key in ((_capi.C_SO_M1, "so_m1"), (_capi.C_SO_M2, "so_m2"), (_capi.C_SNO_M1, "sno_m1"), (_capi.C_SNO_M2, "sno_m2"),
+                             (_capi.C_KLA_LAST, "kla_last"), (_capi.C_EC_LAST, "ec_last")):
+                assert np.allclose(cc[row], ora.envs[key], rtol=1e-9, atol=1e-12), key
+        return xx, torch.from_numpy(cc).cuda()
+
+    x, ctrl = lockstep(6)
+    assert torch.equal(ctrl[_capi.C_SO_M1], x[8]) and torch.equal(ctrl[_capi.C_SNO_M1], x[9])          # implicit now
+    # an import of memories that are not the plant's values: the next step must use THEM (the oracle gets the same rows)
+    ctrl2 = ctrl.clone()
+    ctrl2[_capi.C_SO_M1] += 0.37; ctrl2[_capi.C_SNO_M1] += 1.25
+    env.set_state(x, ctrl2)
+    x3, ctrl3 = env.get_state()
+    assert torch.equal(ctrl3[_capi.C_SO_M1], ctrl2[_capi.C_SO_M1]) and torch.equal(ctrl3[_capi.C_SNO_M1], ctrl2[_capi.C_SNO_M1])
+    x, ctrl = lockstep(1)                          # (the oracle was loaded with the same injected rows)
+    lockstep(3)
+    # a fused rollout in between reads the implicit memories and leaves explicit rows behind
+    x, ctrl = env.get_state()
+    ref = G.SbrOSVec(n, out_dtype=torch.float64)
+    ref.set_state(x, ctrl)
+    _, acts = env.rollout(5, policy_seed=3, return_actions=True)
+    for c in range(5):
+        ref.step(acts[c])
+    xa, ca = env.get_state(); xb, cb = ref.get_state()
+    assert gate(_np(xa).T, _np(xb).T).max() < 1e-6 and torch.allclose(ca, cb, rtol=1e-11, atol=1e-13)
+    assert torch.equal(ca[_capi.C_SO_M1], xa[8]) and torch.equal(ca[_capi.C_SNO_M1], xa[9])
+    ref.close()
+    # ... and stepping on from there, through the done call (whose terminal phases move x away from the memories)
+    xx, cc = env.get_state()
+    calls_left = 463 - int(cc[_capi.C_STEPS, 0].item())
+    x, ctrl = lockstep(calls_left)
+    assert bool((ctrl[_capi.C_DONE] == 1).all())
+    assert not torch.equal(ctrl[_capi.C_SO_M1], x[8])              # So after the idle phase is not the reaction phases' last So
+    env.close()
