@@ -7,7 +7,7 @@
 //              obs/state, and the terminal phases on the last call of an episode
 //   k_rollout  n_steps fused step()s with an on-device Philox policy, plant state stays in VGPRs
 //   k_cycle_reset, k_cycle   the per-cycle env SBR-v2: one launch = one whole 12 h cycle (528 control intervals)
-//   k_export, k_import       public <-> internal controller layout
+//   k_export, k_import, k_m1_explicit   public <-> internal controller layout; implicit So[-1] / Sno[-1] made explicit
 //   k_stats    wavefront (DPP) reductions of a per-env vector -> {sum,min,max,count}
 //   k_rhs, k_normals, k_scenarios, k_fill   known-answer helpers for the parity tests, the scenario draw, handle init
 // What bounds them and how the arithmetic is organised for it: sbr_device.h (sbr_rates, sbr_rk4), DESIGN.md sections 3 and 5.
@@ -220,6 +220,17 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
     } else {
 #pragma unroll
         for (int r = 0; r < SBR_NCTRL; ++r) out[(int64_t)r * b.n + i] = v[r];
+    }
+}
+// makes implicit So[-1] / Sno[-1] explicit (sbr_set_state with a plant only)
+__global__ __launch_bounds__(SBR_BLOCK) void k_m1_explicit(SbrBuf b) {
+    const uint32_t l = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK;
+    if (i0 + l >= b.n) return;
+    const int m = (int)CTRL(R_META);
+    if ((m & SBR_META_M1I) != 0) {
+        CTRL(R_SO_M1) = XROW(8); CTRL(R_SNO_M1) = XROW(9);
+        CTRL(R_META) = (double)(m & ~SBR_META_M1I);
     }
 }
 __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const double* __restrict__ in) {
@@ -1433,7 +1444,15 @@ int sbr_set_state(sbr_env* e, const double* x, const double* ctrl, void* stream)
     if (!e) return SBR_ERR_INVALID;
     ON_DEVICE(e);
     const size_t nb = (size_t)e->n * sizeof(double);
-    if (x) HIP_TRY(e, hipMemcpyAsync(e->buf.x, x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (x) {
+        // a plant without controller rows: So[-1] / Sno[-1] of envs that hold them implicitly (x[8], x[9] of the OLD plant)
+        // are written out first, so that replacing the plant does not replace the controllers' memories with it
+        if (!ctrl) {
+            hipLaunchKernelGGL(k_m1_explicit, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->buf);
+            HIP_TRY(e, hipGetLastError());
+        }
+        HIP_TRY(e, hipMemcpyAsync(e->buf.x, x, SBR_NX * nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     if (ctrl) {
         hipLaunchKernelGGL(k_import, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, ctrl);
         HIP_TRY(e, hipGetLastError());

@@ -1784,6 +1784,14 @@ def test_implicit_so_sno_memories_across_every_writer(G, tables):
     assert torch.equal(ctrl3[_capi.C_SO_M1], ctrl2[_capi.C_SO_M1]) and torch.equal(ctrl3[_capi.C_SNO_M1], ctrl2[_capi.C_SNO_M1])
     x, ctrl = lockstep(1)                          # (the oracle was loaded with the same injected rows)
     lockstep(3)
+    # a plant WITHOUT controller rows must not drag the memories along (they were x[8], x[9] of the old plant)
+    x, ctrl = env.get_state()
+    x_new = x.clone(); x_new[8] += 0.11; x_new[9] += 0.21
+    env.set_state(x_new, None)
+    x4, ctrl4 = env.get_state()
+    assert torch.equal(x4, x_new) and torch.equal(ctrl4, ctrl)
+    env.set_state(x, None)
+    lockstep(2)
     # a fused rollout in between reads the implicit memories and leaves explicit rows behind
     x, ctrl = env.get_state()
     ref = G.SbrOSVec(n, out_dtype=torch.float64)
