@@ -543,6 +543,16 @@ def main():
                                          "host_in_reset_issue": acct["reset_issue_ms"],
                                          "since_clock_priming": gap_ms},
                      "fp64_valu": fp64,
+                     # what three measured numbers add up to when nothing overlaps (one wave per SIMD): the launch's memory traffic
+                     # at the roofline's own rate + PIDs and RK4 at the single-wave issue rate (stamp build, both batch sizes) + the
+                     # period of an EMPTY dependent launch of this footprint (graph replay).  DESIGN.md section 5.
+                     "serial_bound": ({"memory_us": traffic / (HBM_PEAK_GBPS * 1e3), "arithmetic_us": 6.3, "dependent_launch_floor_us": 1.82,
+                                       "sum_us": traffic / (HBM_PEAK_GBPS * 1e3) + 6.3 + 1.82,
+                                       "frac_at_bound": n_local * ALGO_BYTES_PER_ENV_STEP / ((traffic / (HBM_PEAK_GBPS * 1e3) + 6.3 + 1.82) * 1e-6)
+                                                        / 1e9 / HBM_PEAK_GBPS,
+                                       "note": "memory_us from `traffic` of this library; the other two are committed measurements "
+                                               "(profiles/r04_step_timeline.log, profiles/r02_notes.md), not taken by this run"}
+                                      if (traffic and not fused and n_local == 65536) else None),
                      "headline": "fp64_valu" if fused else "hbm",
                      "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
                               "513-byte per-step CONVENTION, not traffic (`traffic` is what really moves); the kernel is bound by float64 "
