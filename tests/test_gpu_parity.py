@@ -1479,6 +1479,10 @@ def test_bench_line_contract(force_dist):
     # both roofline figures travel with the line: `frac` of the timed launches, `frac_episode` from the committed kernel trace of
     # whole episodes of this very library (None, with the reason, when no such trace is committed)
     assert ("frac_episode" in r) and (r["frac_episode"] is None or 0.1 < r["frac_episode"] <= r["frac"] * 1.1) and r["frac_episode_source"]
+    # ... and so does the no-overlap bound they are to be read against (memory at the roofline's rate + arithmetic + launch floor)
+    sb = r["serial_bound"]
+    assert sb is None or (abs(sb["sum_us"] - (sb["memory_us"] + sb["arithmetic_us"] + sb["dependent_launch_floor_us"])) < 1e-9
+                          and 0.25 < sb["frac_at_bound"] < 0.45 and abs(sb["memory_us"] - r["traffic"] / 8e6) < 1e-6)
     # PMC traffic is a committed constant: present only if profiles/ holds a profile of THIS library (same source hash)
     assert (r["traffic"] is None) or ("committed constant" in r["traffic_unit"] and r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"])
     assert r["traffic"] is not None or r["traffic_unit"]
