@@ -62,6 +62,11 @@ def table(tag):
          "%.3ge10 control intervals/s; %.0f %% of the float64 vector peak, %.0f %% of the issue slots; %.2f B per interval moved"
          % (cyc["value"] / 1e10, 100 * cyc["roofline"]["fp64_valu"]["frac"], 100 * cyc["roofline"]["fp64_valu"]["issue_slot_frac"],
             cy["hbm_bytes_per_env_step"]), "`%s_bench_cycle.json`" % tag),
+        ("larger batches per launch (`--envs-per-gpu`; two and four waves per SIMD)",
+         "; ".join("%s envs: %.3ge9 env-steps/s, %.1f µs per launch, %.3f of the prescribed roofline"
+                   % ("{:,}".format(n).replace(",", " "), b["value"] / 1e9, b["roofline"]["avg_launch_us"], b["roofline"]["frac"])
+                   for n, b in ((n, _j(tag, "bench_config2_n%d" % n)) for n in (131072, 262144))),
+         "`%s_bench_config2_n131072.json`, `%s_bench_config2_n262144.json`" % (tag, tag)),
         ("configs[1] (4 096 envs, 64 wavefronts: latency only)",
          "%.3ge8 env-steps/s, %.2f µs per launch" % (c1["value"] / 1e8, c1["roofline"]["avg_launch_us"]), "`%s_bench_config1.json`" % tag),
         ("CPU baseline on the GPU box (C port of the same algorithm)",
