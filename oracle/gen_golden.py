@@ -19,6 +19,7 @@ import io
 import os
 import sys
 import types
+import warnings
 
 sys.dont_write_bytecode = True  # never write __pycache__ into the read-only tree
 os.environ.setdefault("MPLBACKEND", "Agg")
@@ -176,9 +177,23 @@ def rhs_kats(M, n=96, seed=7):
 
 
 # --------------------------------------------------------------------------- episodes
-def run_episode(M, seed, actions, rnd_override=None):
-    """One SbrOS episode; returns a dict of arrays (per call, per interval, terminal)."""
+def run_episode(M, seed, actions, rnd_override=None, scenario=None):
+    """One SbrOS episode; returns a dict of arrays (per call, per interval, terminal).
+
+    `scenario`: SbrOS.reset() hard-codes `buffer_tank.influent.buffer_tank(6)` (gym_SBR_oneshot.py:180, with SbrEnv4's
+    `np.random.choice(8, 1)` left in a comment).  To record the other seven plants the harness rebinds the NAME
+    `buffer_tank` in the imported module object to a namespace whose function ignores the literal 6 and calls the
+    reference's own buffer_tank3.influent.buffer_tank(scenario) - no file of the reference is touched, and the module
+    buffer_tank3 itself (shared with the other envs) stays as it is.
+    The reference has no guards: a policy can drive a concentration negative towards a Monod pole, after which LSODA may
+    return garbage and Sim_Settling_Drawing may raise (seen: OverflowError at :2338, scenario 4 under constant [2, 5]).
+    An exception ends the recording; `crashed` / `crash_call` say so and everything recorded up to there is kept."""
     env = M.SbrOS()
+    real_bt = M.buffer_tank
+    if scenario is not None:
+        from gym_SBR.envs import buffer_tank3
+        M.buffer_tank = types.SimpleNamespace(influent=types.SimpleNamespace(
+            buffer_tank=lambda _six, _f=buffer_tank3.influent.buffer_tank, _s=int(scenario): _f(_s)))
     rec = {}
     box = {}
     real_randn = np.random.randn
@@ -248,7 +263,9 @@ def run_episode(M, seed, actions, rnd_override=None):
             obs0 = env.reset()
     finally:
         np.random.randn = real_randn
+        M.buffer_tank = real_bt
     rec["seed"] = np.int64(seed)
+    rec["scenario"] = np.int64(6 if scenario is None else scenario)
     rec["rnd"] = box["rnd"]
     rec["influent_mixed"] = np.array(M.influent_mixed, dtype=np.float64)  # [0] already = Qin/T_fill
     rec["x0_init"] = np.array(M.x0_init, dtype=np.float64)
@@ -271,12 +288,18 @@ def run_episode(M, seed, actions, rnd_override=None):
     per = {k: [] for k in keys}
     done = False
     k = 0
+    crash = ""
     with contextlib.redirect_stdout(io.StringIO()):
         while not done:
             a = actions[k]
             n_before = len(intervals)
             calls.append(k)
-            obs, state, reward, done, _ = env.step([float(a[0]), float(a[1])])
+            try:
+                obs, state, reward, done, _ = env.step([float(a[0]), float(a[1])])
+            except (ArithmeticError, ValueError) as ex:          # the reference itself raised (see the docstring)
+                crash = "%s: %s" % (type(ex).__name__, ex)
+                del intervals[n_before:]                          # the crashed call's intervals are not part of the record
+                break
             n_iv = len(intervals) - n_before
             last = intervals[-1]
             per["t"].append(M.t)
@@ -307,6 +330,9 @@ def run_episode(M, seed, actions, rnd_override=None):
         rec["step_" + kk] = np.asarray(per[kk], dtype=np.float64 if kk not in ("done", "n_intervals") else np.int64)
     rec["actions"] = np.asarray(actions[:k], dtype=np.float64)
     rec["n_calls"] = np.int64(k)
+    rec["crashed"] = np.int64(bool(crash))
+    rec["crash_call"] = np.int64(k if crash else -1)
+    rec["crash_msg"] = np.asarray(crash)
     rec["iv_kind"] = np.asarray([iv["kind"] for iv in intervals], dtype=np.int64)
     rec["iv_call"] = np.asarray([iv["call"] for iv in intervals], dtype=np.int64)
     for f in ("t_start", "t_end", "u_DO", "u_EC", "Kla", "EC", "ie_DO", "ie_EC"):
@@ -493,6 +519,80 @@ def episode_cases():
     }
 
 
+def scenario_cases():
+    """The plants SbrOS never runs by itself: every influent scenario 0..7 (buffer_tank3.py:18-1197; 2-5 scale Ss, Xs, Si, Xi
+    by 1.5, :268-287, :416-438), which bench.py's workload (scenarios 4..7) and `SbrEnv4`-style random resets
+    (gym_SBR_env4.py:107) do run.  Per scenario:
+      phys  - the bench's physical policy, seeded u_DO ~ U[0, 2.5], u_EC ~ U[0, 15] per call (bench.py `--policy physical`);
+      c25   - the constant action [2, 5] of SURVEY.md / BASELINE.md; it leaves the model's domain on scenarios 0..5
+              (ammonia is driven negative towards the pole at -K_NH; `domain_exit_call` records where);
+      c1_7  - scenarios 4 and 5 only: the constant [1.25, 7.5] (the physical policy's mean), which stays inside the domain
+              where [2, 5] does not."""
+    n = 470
+    cases = {}
+    for s in range(8):
+        rs = np.random.RandomState(7000 + s)
+        cases["scn%d_phys" % s] = (100 + s, np.column_stack([rs.uniform(0, 2.5, n), rs.uniform(0, 15, n)]), s)
+        cases["scn%d_c25" % s] = (200 + s, np.tile([2.0, 5.0], (n, 1)), s)
+        if s in (4, 5):
+            cases["scn%d_c1_7" % s] = (300 + s, np.tile([1.25, 7.5], (n, 1)), s)
+    return cases
+
+
+# slim record of a scenario episode: everything the bit-identity, open-loop and closed-loop tests read; not the 9-or-10
+# LSODA output rows of every interval nor the dense trajectory lists (pinned on the six scenario-6 episodes)
+SCENARIO_DROP = ("iv_x_rows", "iv_t_rows", "step_x_start", "traj_So_t", "traj_Sno_t", "traj_Snh_t", "traj_t_t", "traj_EC",
+                 "traj_dcv_EC", "traj_ie_EC", "traj_e_EC", "traj_u_EC_t", "reset_So", "reset_Sno")
+
+
+def domain_exit(rec):
+    """First call after which the plant is outside the model's domain, by the thresholds of the library's sticky status flags
+    (include/sbr_amd.h SBR_ST_NEGATIVE: one of Ss, Xs, Xbh, So, Sno, Snh below -1e-6; NONFINITE), or -1."""
+    xe = rec["step_x_end"]
+    if len(xe) == 0:
+        return np.int64(0)
+    bad = (xe[:, [2, 4, 5, 8, 9, 10]] < -1e-6).any(axis=1) | ~np.isfinite(xe).all(axis=1)
+    hit = np.where(bad)[0]
+    return np.int64(hit[0] if len(hit) else -1)
+
+
+def near_pole(rec):
+    """First call after which a Monod term x/(K + x) is within 50 % of its pole (SBR_ST_NEAR_POLE: Ss < -K_S/2, So < -K_OH/2,
+    Sno < -K_NO/2 or Snh < -K_NH/2, constants of gym_SBR_oneshot.py:118-119), or -1.  From there on the reference's own
+    default-tolerance LSODA result is tens of gates away from its own tight-tolerance one: comparisons end here."""
+    xe = rec["step_x_end"]
+    bad = (xe[:, 2] < -5.0) | (xe[:, 8] < -0.1) | (xe[:, 9] < -0.25) | (xe[:, 10] < -0.5) | ~np.isfinite(xe).all(axis=1)
+    hit = np.where(bad)[0]
+    return np.int64(hit[0] if len(hit) else -1)
+
+
+def scenario_episodes(M, out, tol=1e-12):
+    import scipy.integrate as si
+    real = M.integrate
+
+    def odeint_tight(func, y0, t, args=(), **kw):
+        kw.setdefault("rtol", tol); kw.setdefault("atol", tol); kw.setdefault("mxstep", 100000)
+        return si.odeint(func, y0, t, args=args, **kw)
+    for name, (seed, acts, scen) in scenario_cases().items():
+        rec = run_episode(M, seed, acts, None, scenario=scen)
+        rec["domain_exit_call"], rec["near_pole_call"] = domain_exit(rec), near_pole(rec)
+        np.savez_compressed(os.path.join(out, "sbros_%s.npz" % name), **{k: v for k, v in rec.items() if k not in SCENARIO_DROP})
+        M.integrate = types.SimpleNamespace(odeint=odeint_tight)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tr = run_episode(M, seed, acts, None, scenario=scen)
+        finally:
+            M.integrate = real
+        tr["domain_exit_call"], tr["near_pole_call"] = domain_exit(tr), near_pole(tr)
+        keys = TIGHT_KEYS + ["scenario", "crashed", "crash_call", "crash_msg", "domain_exit_call", "near_pole_call"]
+        np.savez_compressed(os.path.join(out, "sbros_%s_tight.npz" % name), odeint_tol=np.float64(tol),
+                            **{k: tr[k] for k in keys if k in tr})
+        print("%-12s calls=%d/%d exit=%d/%d pole=%d/%d crashed=%d/%d return=%.12g / %.12g" % (
+            name, rec["n_calls"], tr["n_calls"], rec["domain_exit_call"], tr["domain_exit_call"], rec["near_pole_call"], tr["near_pole_call"], rec["crashed"], tr["crashed"],
+            rec["episode_return"], tr["episode_return"]))
+
+
 # what the closed-loop parity test needs from an episode of the reference run at tight integrator tolerance
 TIGHT_KEYS = ["seed", "rnd", "influent_mixed", "x_postfill", "actions", "n_calls", "step_t", "step_x_end", "step_Kla",
               "step_EC", "step_reward", "step_done", "step_n_intervals", "term_Qw", "term_x_after_idle", "episode_return"]
@@ -525,13 +625,15 @@ def tight_episodes(M, out, tol=1e-12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    ap.add_argument("--only", default="", help="regenerate one fixture group only: reward_oci | tight")
+    ap.add_argument("--only", default="", help="regenerate one fixture group only: reward_oci | tight | scenarios")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     M = import_reference()
     if args.only == "tight":
         return tight_episodes(M, out)
+    if args.only == "scenarios":
+        return scenario_episodes(M, out)
     np.savez_compressed(os.path.join(out, "reward_oci_kat.npz"), **reward_oci_kats())
     if args.only == "reward_oci":
         return
@@ -563,6 +665,7 @@ def main():
     print("SBR-v2: %d cycles, phases per cycle %s, rewards %s" % (len(acts), rec["phase_count"].tolist(),
                                                                   np.round(rec["reward"], 6).tolist()))
     tight_episodes(M, out)
+    scenario_episodes(M, out)
     print("wrote fixtures to", out)
 
 

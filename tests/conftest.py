@@ -8,7 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-EPISODES = ["const_2_5", "random_a", "random_b", "zeros", "max", "det_influent"]
+EPISODES = ["const_2_5", "random_a", "random_b", "zeros", "max", "det_influent"]          # scenario 6, what SbrOS itself runs
+# round 5: the reference's SbrOS on EVERY influent scenario (oracle/gen_golden.py scenario_cases: the harness redirects the
+# hard-coded buffer_tank(6) of gym_SBR_oneshot.py:180).  phys = the bench's physical policy, c25 = constant [2, 5] (leaves the
+# model's domain on scenarios 0..5), c1_7 = constant [1.25, 7.5] on the two bench scenarios where [2, 5] does not stay physical
+SCENARIO_EPISODES = ["scn%d_%s" % (s, p) for s in range(8) for p in ("phys", "c25")] + ["scn4_c1_7", "scn5_c1_7"]
+BENCH_SCENARIOS = (4, 5, 6, 7)                # bench.py --policy physical: scenario = 4 + global id mod 4
 
 
 def pytest_configure(config):
@@ -17,6 +22,15 @@ def pytest_configure(config):
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def valid_calls(e):
+    """Number of leading calls of a fixture episode on which parity with the reference is DEFINED: all of them, or those before
+    the plant comes within 50 % of a Monod pole (`near_pole_call`, the library's SBR_ST_NEAR_POLE; scenario fixtures only).
+    From there on the reference's own default-tolerance LSODA is tens of gates from its own 1e-12 run."""
+    n = int(e["n_calls"])
+    pole = int(e["near_pole_call"]) if "near_pole_call" in e.files else -1
+    return n if pole < 0 else min(n, pole)
 
 
 @pytest.fixture(scope="session")

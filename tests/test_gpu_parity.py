@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import EPISODES, gate, golden, obs_tolerance
+from conftest import BENCH_SCENARIOS, EPISODES, SCENARIO_EPISODES, gate, golden, obs_tolerance, valid_calls
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -221,11 +221,15 @@ def test_float32_outputs_are_the_rounded_float64_outputs(G, tables):
 def test_open_loop_intervals_from_reference_states(G):
     """North star: 'match the reference odeint step on identical initial states'.  Every one of the 466
     intervals of an episode is started from the reference's own state and controller memory (set_state),
-    one step() is run on the device and the end state must be inside the gate of the reference's."""
+    one step() is run on the device and the end state must be inside the gate of the reference's.
+    Round 5: on ALL EIGHT influent scenarios (the 18 scenario episodes captured from the reference with the harness
+    redirecting its hard-coded buffer_tank(6)), under the bench's physical policy and constant actions, on every call that
+    starts from a state not within 50 % of a Monod pole (conftest.valid_calls)."""
     from gym_sbr2_amd import _capi
-    for name in ("const_2_5", "random_b", "zeros"):
+    worst = {}
+    for name in ["const_2_5", "random_b", "zeros"] + SCENARIO_EPISODES:
         e = golden("sbros_" + name)
-        ncall = int(e["n_calls"])
+        ncall = min(int(e["n_calls"]), valid_calls(e) + 1)
         calls = [k for k in range(1, ncall - 1) if e["step_n_intervals"][k] == 1]
         n = len(calls)
         x = np.zeros((_capi.NX, n)); ctrl = np.zeros((_capi.NCTRL, n))
@@ -248,6 +252,7 @@ def test_open_loop_intervals_from_reference_states(G):
         ref_x = e["step_x_end"][calls]
         g = gate(x1, ref_x)
         assert g.max() <= 1.0, (name, g.max())                       # oracle: worst 0.24 (So at aeration switch-on)
+        worst[name] = float(g.max())
         # controller outputs are computed before the integration: they equal the reference's to rounding
         assert np.abs(c1[_capi.C_KLA_LAST] - e["step_Kla"][calls]).max() < 1e-10       # Kla up to 240
         assert np.abs(c1[_capi.C_EC_LAST] - e["step_EC"][calls]).max() < 1e-16         # EC up to 5e-4
@@ -259,6 +264,73 @@ def test_open_loop_intervals_from_reference_states(G):
         ref_o = np.c_[e["step_obs_DO"][calls], e["step_obs_EC"][calls]]
         assert np.all(np.abs(_np(o) - ref_o) <= obs_tolerance(ref_x)), np.abs(_np(o) - ref_o).max()
         env.close()
+    print("[info] open loop, device vs reference, worst gate per episode: " + ", ".join("%s %.3f" % kv for kv in worst.items()))
+    assert max(worst.values()) <= 0.6                                # oracle: 0.51 (random_b); 0.34 on the scenario episodes
+
+
+def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(G, tables):
+    """The bench's own workload pinned to the reference: the 18 scenario episodes as one batch, chained
+    over the whole episode on the device, against the unmodified reference run with odeint at rtol = atol = 1e-12
+    (sbros_scn*_tight.npz) and against the oracle.  Inside the gate on every call on which parity is defined - all 463 calls,
+    terminal phases, return and wastage included, for every episode on the bench's scenarios 4..7 under the physical policy -
+    and up to the call at which an episode comes near a pole elsewhere; from there on the device must still equal the oracle
+    in lockstep (same arithmetic, same garbage) and raise the library's NEAR_POLE flag."""
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    names = SCENARIO_EPISODES
+    E = [golden("sbros_" + nm) for nm in names]
+    T = [golden("sbros_%s_tight" % nm) for nm in names]
+    n, ncall = len(E), 463
+    scen = np.array([int(e["scenario"]) for e in E], dtype=np.int32)
+    rnd = np.stack([e["rnd"] for e in E])
+    nv = np.array([min(valid_calls(e), valid_calls(t)) for e, t in zip(E, T)])
+    acts = np.stack([e["actions"][:ncall] for e in E], axis=1).astype(np.float64)
+    env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64)
+    ora = O.OracleBatch(n)
+    obs0 = _np(env.reset(scenario=scen, rnd=rnd)).copy()
+    ora.reset(ora.mix(means, stds, scen, rnd))
+    x, _ = env.get_state()
+    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0         # fill phase vs the reference, every scenario
+    for i, e in enumerate(E):
+        assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6
+    worst_tight, worst_gold = np.zeros(n), np.zeros(n)
+    xd, cd = env.get_state()
+    for c in range(ncall):
+        # lockstep with the oracle: re-synchronised to the device's own state before every call, so that the comparison stays
+        # rounding-level also where the closed loop amplifies differences without bound (near a pole)
+        ora.load_state(_np(xd), _np(cd))
+        o, s, r, d = env.step(torch.from_numpy(acts[c]).cuda())
+        ora.step(acts[c])
+        xd, cd = env.get_state()
+        x, ctrl = _np(xd).T, _np(cd)
+        gl = gate(x, ora.envs["x"]).max(axis=1)
+        live = c < nv
+        assert gl[live].max() < 1e-6, (c, gl.max())
+        assert np.isfinite(x).all()
+        assert np.array_equal(ctrl[_capi.C_STATUS], ora.envs["status"]), c                # flags agree exactly
+        assert np.array_equal(_np(d), [int(e["step_done"][c]) for e in E])
+        assert np.array_equal(ctrl[_capi.C_T], [e["step_t"][c] for e in E])
+        if c < ncall - 1:
+            for i in np.where(live)[0]:
+                worst_tight[i] = max(worst_tight[i], gate(x[i], T[i]["step_x_end"][c]).max())
+                worst_gold[i] = max(worst_gold[i], gate(x[i], E[i]["step_x_end"][c]).max())
+                assert abs(_np(r)[i] - T[i]["step_reward"][c]) < 5e-7
+    print("[info] scenario episodes, device vs reference(1e-12), worst gate: " +
+          ", ".join("%s %.3f" % (nm, w) for nm, w in zip(names, worst_tight)))
+    for i, nm in enumerate(names):
+        assert worst_tight[i] <= 1.0 and worst_gold[i] <= 1.0, (nm, worst_tight[i], worst_gold[i])
+        if nv[i] == ncall:                                            # the whole episode is inside the domain of parity
+            t = T[i]
+            assert gate(x[i], t["term_x_after_idle"]).max() <= 1.0, nm
+            assert abs(ctrl[_capi.C_RETURN][i] / float(t["episode_return"]) - 1) < 1e-5
+            assert abs(ctrl[_capi.C_QW][i] / float(t["term_Qw"]) - 1) < 1e-5
+            near = int(ctrl[_capi.C_STATUS][i]) & _capi.ST_NEAR_POLE
+            assert not near, nm
+        else:
+            assert int(ctrl[_capi.C_STATUS][i]) & _capi.ST_NEAR_POLE, nm          # the library says so itself
+    full = [nm for i, nm in enumerate(names) if nv[i] == ncall]
+    assert all(("scn%d_phys" % s) in full for s in BENCH_SCENARIOS) and len(full) == 9
+    env.close()
 
 
 def test_config2_4096_envs_full_episode_against_oracle(G, tables):
