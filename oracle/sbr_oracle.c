@@ -34,6 +34,8 @@ typedef struct {
     double cyc_Kc, cyc_tauI, cyc_tauD, cyc_dt;
     double x0[NX];
     int32_t substeps, out_f64, terminal, reward_kind, act_f64, random_scenario;
+    int32_t scheme;                 /* 0: RK4 x substeps per control interval; 1: adaptive Butcher-5 (b5a_interval) */
+    int32_t pad_;
 } sbro_params;
 
 /* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
@@ -52,6 +54,8 @@ typedef struct {
     double span;                    /* t_range[-1]-t_range[0] of the last interval */
     int32_t n_rows;                 /* 9 or 10: len(t_range) of the last interval */
     int32_t n_intervals;            /* intervals run by the last step() call */
+    int32_t scheme_steps;           /* scheme 1: step count of the last interval (0 = fell back to the RK4 substeps) */
+    int32_t pad_;
 } sbro_env;
 
 static double status_bits(const sbro_params* p, const double* x, double status);
@@ -85,6 +89,7 @@ void sbro_default_params(sbro_params* p) {
                                   3.790463057094611};
     memcpy(p->x0, x0, sizeof x0);
     p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->reward_kind = 0; p->act_f64 = 0; p->random_scenario = 0;
+    p->scheme = 0; p->pad_ = 0;
 }
 
 int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }
@@ -224,6 +229,79 @@ static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, 
     }
     const double s_end = x[0] / v0;
     for (int i = 1; i < NX; ++i) x[i] = x[i] / s_end;
+}
+
+/* ---------------------------------------------------------------------------------- scheme 1 ("B5A", round 5)
+ * One control interval by Butcher's six-stage fifth-order scheme with a step count chosen per interval from the plant's own
+ * state.  Same operations in the same order as oracle/sbr_ref.py b5a_plan / b5_step / b5a_reaction (bit-identical); the
+ * reasoning is written there and in DESIGN.md 4.3. */
+#define B5A_SO_SLAVED 1e-9
+#define B5A_Z1 0.3
+#define B5A_Z2 1.0
+#define B5A_Z_STAB 3.0
+
+static void b5a_rhs(const sbro_params* p, const double* y, double v0, double kla, double ec, int hold_so, double* k) {
+    if (ec != 0.0) rhs_reaction_w(p, y, v0, kla, ec, k);
+    else sbro_rhs_reaction(p, y, kla, ec, k);
+    if (hold_so) k[8] = 0.0;
+}
+
+/* returns the step count (0 = fell back to RK4 x p->substeps) */
+static int b5a_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
+    static const double A21 = 0.25, A31 = 0.125, A32 = 0.125, A42 = -0.5, A43 = 1.0, A51 = 3.0 / 16.0, A54 = 9.0 / 16.0,
+                        A61 = -3.0 / 7.0, A62 = 2.0 / 7.0, A63 = 12.0 / 7.0, A64 = -12.0 / 7.0, A65 = 8.0 / 7.0,
+                        B1 = 7.0 / 90.0, B3 = 32.0 / 90.0, B4 = 12.0 / 90.0, B5 = 32.0 / 90.0, B6 = 7.0 / 90.0;
+    const double v0 = x[0];
+    double k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX];
+    b5a_rhs(p, x, v0, kla, ec, 0, k1);
+    /* the plan */
+    const double ss = x[2], xbh = x[5], xba = x[6], so = x[8], snh = x[10];
+    const double a1 = ((1 - p->Yh) / p->Yh) * p->muH * (ss / (p->Ks + ss)) * xbh;
+    const double a3 = ((4.57 - p->Ya) / p->Ya) * p->muA * (snh / (p->Knh + snh)) * xba;
+#define LAM(s_) (a1 * p->Koh / ((p->Koh + (s_)) * (p->Koh + (s_))) + a3 * p->Koa / ((p->Koa + (s_)) * (p->Koa + (s_))) + kla)
+    const int slaved = (fabs(so) < B5A_SO_SLAVED) && (kla * p->So_sat * span < B5A_SO_SLAVED);
+    const double proj = so + k1[8] * span;
+    const double lo1 = proj < so ? proj : so;
+    const double so_lo = lo1 > 0.0 ? lo1 : 0.0;
+    const double z_ub = LAM(so_lo) * span;
+    const double lam0 = LAM(0.0);
+#undef LAM
+    const int n = slaved ? 2 : (z_ub < B5A_Z1 ? 1 : (z_ub < B5A_Z2 ? 2 : 4));
+    if (!slaved && n == 4 && lam0 * span / 4 > B5A_Z_STAB) {
+        rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
+        return 0;
+    }
+    const double h = span / n;
+    if (slaved) k1[8] = 0.0;
+    for (int s = 0; s < n; ++s) {
+        if (s > 0) b5a_rhs(p, x, v0, kla, ec, slaved, k1);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A21) * k1[i];
+        b5a_rhs(p, y, v0, kla, ec, slaved, k2);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A31) * k1[i] + (h * A32) * k2[i];
+        b5a_rhs(p, y, v0, kla, ec, slaved, k3);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A42) * k2[i] + (h * A43) * k3[i];
+        b5a_rhs(p, y, v0, kla, ec, slaved, k4);
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A51) * k1[i] + (h * A54) * k4[i];
+        b5a_rhs(p, y, v0, kla, ec, slaved, k5);
+        for (int i = 0; i < NX; ++i)
+            y[i] = x[i] + (h * A61) * k1[i] + (h * A62) * k2[i] + (h * A63) * k3[i] + (h * A64) * k4[i] + (h * A65) * k5[i];
+        b5a_rhs(p, y, v0, kla, ec, slaved, k6);
+        for (int i = 0; i < NX; ++i)
+            x[i] = x[i] + (h * B1) * k1[i] + (h * B3) * k3[i] + (h * B4) * k4[i] + (h * B5) * k5[i] + (h * B6) * k6[i];
+    }
+    if (ec != 0.0) {
+        const double s_end = x[0] / v0;
+        for (int i = 1; i < NX; ++i) x[i] = x[i] / s_end;
+    }
+    if (slaved) x[8] = x[8] / (1.0 + lam0 * span);
+    return n;
+}
+
+/* scheme-aware integration of one reaction interval (python: SbrOsRef._integrate); returns the step count (-1: scheme 0) */
+int sbro_reaction_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
+    if (p->scheme == 1) return b5a_interval(p, x, span, kla, ec);
+    rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
+    return -1;
 }
 
 void sbro_rk4(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,
@@ -401,7 +479,7 @@ static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
     if (ec < p->EC_min) { ec = p->EC_min; e->ie_ec = e->ie_ec - err2 * p->dt; }
     else if (ec > p->EC_max) { ec = p->EC_max; e->ie_ec = e->ie_ec - err2 * p->dt; }
     memcpy(e->x_start, e->x, sizeof e->x_start);
-    rk4_span(p, 0, e->x, t1 - t0, p->substeps, kla, ec, 0);
+    e->scheme_steps = sbro_reaction_interval(p, e->x, t1 - t0, kla, ec);
     for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];
     e->kla_hist[KLA_HIST - 1] = kla;
     e->kla_sum = e->kla_sum + kla;

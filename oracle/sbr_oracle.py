@@ -22,7 +22,8 @@ class Params(C.Structure):
         ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32)]
+        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32),
+        ("scheme", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Env(C.Structure):
@@ -34,7 +35,7 @@ class Env(C.Structure):
                 ("kla_hist", C.c_double * KLA_HIST),
                 ("qw", C.c_double), ("ret", C.c_double), ("steps", C.c_double), ("done", C.c_double),
                 ("status", C.c_double), ("kla_sum", C.c_double), ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
-                ("n_rows", C.c_int32), ("n_intervals", C.c_int32)]
+                ("n_rows", C.c_int32), ("n_intervals", C.c_int32), ("scheme_steps", C.c_int32), ("pad_", C.c_int32)]
 
 
 ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "f8"), ("sno_m1", "f8"),
@@ -42,7 +43,8 @@ ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "
                       ("ec_prev", "f8"), ("u_do", "f8"), ("u_ec", "f8"), ("kla_hist", "f8", KLA_HIST),
                       ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("status", "f8"), ("kla_sum", "f8"),
                       ("influent", "f8", NX),
-                      ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4")], align=True)
+                      ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4"), ("scheme_steps", "i4"),
+                      ("pad_", "i4")], align=True)
 
 
 def _src_hash():
@@ -228,6 +230,18 @@ def rk4(kind, x, span, n, kla, ec=0.0, loading=None, params=None):
     lib().sbro_rk4(C.byref(p), C.c_int(kind), _p(x), C.c_double(span), C.c_int(n), C.c_double(kla), C.c_double(ec),
                    _p(ld))
     return x
+
+
+def reaction_interval(x, span, kla, ec=0.0, params=None, scheme=1):
+    """One reaction interval by the scheme-aware integrator of the C oracle (scheme 1: the adaptive Butcher-5 of round 5).
+    Returns (x_end, step count; 0 = fell back to RK4, -1 = scheme 0)."""
+    p = params if params is not None else default_params()
+    p.scheme = scheme
+    x = np.array(x, dtype=np.float64)
+    fn = lib().sbro_reaction_interval
+    fn.restype = C.c_int
+    n = fn(C.byref(p), _p(x), C.c_double(span), C.c_double(kla), C.c_double(ec))
+    return x, int(n)
 
 
 NCYC_DIAG = 12   # qw, EQI, OCI, Ntot, COD, Snh, BOD5, Sno (effluent), mean Kla of phases 3, 5, 8, Xf

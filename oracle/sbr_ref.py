@@ -170,6 +170,97 @@ def rk4_reaction_w(x, t0, t1, n, kla, ec):
     return x
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# scheme 1 ("B5A", round 5): a control interval by Butcher's six-stage fifth-order Runge-Kutta scheme with a step count
+# chosen PER INTERVAL from the plant's own state, instead of ten classical RK4 substeps.  Still an explicit fixed-formula
+# integration of the reference's reaction_dxdt (gym_SBR_oneshot.py:1658-1787) with Kla and EC held; what changes is where
+# the right-hand-side evaluations are spent (scripts/analysis/rhs_study.py):
+#   * the only stiff mode of the system is the relaxation of dissolved oxygen,
+#         lam(So) = a1 K_OH/(K_OH+So)^2 + a3 K_OA/(K_OA+So)^2 + Kla,   a1, a3 from rho1, rho3 of :1660-1668;
+#     every other mode has |lambda| t_delta <= ~1.3, which ONE fifth-order step resolves to 1e-7;
+#   * "slaved" intervals - |So| < 1e-9 and an aeration that could not lift it above that within the interval, i.e. the anoxic
+#     phases once the oxygen is used up (So is 1e-10 ... 1e-52 in the reference there) - hold So during the steps and damp it
+#     afterwards by 1/(1 + lam(0) span): TWO steps (one step's local error, <= 0.035 of the gate, is amplified past the
+#     gate by the NO3-PID -> dosing loop in the golden episode random_b; two steps: 0.0008);
+#   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span, So_lo = the lowest So a linear projection over the interval
+#     reaches (consumption slows as So falls, so the projection bounds So from below and z from above);
+#   * a four-step interval whose worst-case lam(0) h exceeds Z_STAB (Butcher-5 is stable on the real axis up to 3.39) falls
+#     back to the RK4 substeps, stable to lam dt = 2.78.
+# oracle/sbr_oracle.c b5a_interval does the same operations in the same order (bit-identical, tests/test_oracle_golden.py).
+B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB = 1e-9, 0.3, 1.0, 3.0
+_A21, _A31, _A32, _A42, _A43, _A51, _A54 = 0.25, 0.125, 0.125, -0.5, 1.0, 3.0 / 16.0, 9.0 / 16.0
+_A61, _A62, _A63, _A64, _A65 = -3.0 / 7.0, 2.0 / 7.0, 12.0 / 7.0, -12.0 / 7.0, 8.0 / 7.0
+_B1, _B3, _B4, _B5, _B6 = 7.0 / 90.0, 32.0 / 90.0, 12.0 / 90.0, 32.0 / 90.0, 7.0 / 90.0
+
+
+def b5a_plan(x, k1_so, span, kla):
+    """(n, slaved, fallback, lam0): the step count of one interval from its start state, the slope of So there (first stage
+    of the first step, which does not depend on the step size), the span and Kla."""
+    ss, xbh, xba, so, snh = x[2], x[5], x[6], x[8], x[10]
+    a1 = ((1 - P.YH) / P.YH) * P.MUH * (ss / (P.KS + ss)) * xbh
+    a3 = ((4.57 - P.YA) / P.YA) * P.MUA * (snh / (P.KNH + snh)) * xba
+
+    def lam(s):
+        return a1 * P.KOH / ((P.KOH + s) * (P.KOH + s)) + a3 * P.KOA / ((P.KOA + s) * (P.KOA + s)) + kla
+    slaved = (abs(so) < B5A_SO_SLAVED) and (kla * P.SO_SAT * span < B5A_SO_SLAVED)
+    proj = so + k1_so * span
+    so_lo = max(0.0, min(so, proj))
+    z_ub = lam(so_lo) * span
+    lam0 = lam(0.0)
+    n = 2 if slaved else (1 if z_ub < B5A_Z1 else (2 if z_ub < B5A_Z2 else 4))
+    fallback = (not slaved) and n == 4 and (lam0 * span / 4 > B5A_Z_STAB)
+    return n, slaved, fallback, lam0
+
+
+def b5_step(f, x, h, k1, hold_so):
+    """One step of Butcher's fifth-order scheme (six stages; J. C. Butcher 1964); k1 = f(x) is passed in.  hold_so: the
+    slope of component 8 is replaced by 0 in every stage."""
+    def ev(y):
+        k = f(y)
+        if hold_so:
+            k[8] = 0.0
+        return k
+    k2 = ev(x + (h * _A21) * k1)
+    k3 = ev(x + (h * _A31) * k1 + (h * _A32) * k2)
+    k4 = ev(x + (h * _A42) * k2 + (h * _A43) * k3)
+    k5 = ev(x + (h * _A51) * k1 + (h * _A54) * k4)
+    k6 = ev(x + (h * _A61) * k1 + (h * _A62) * k2 + (h * _A63) * k3 + (h * _A64) * k4 + (h * _A65) * k5)
+    return x + (h * _B1) * k1 + (h * _B3) * k3 + (h * _B4) * k4 + (h * _B5) * k5 + (h * _B6) * k6
+
+
+def b5a_reaction(x, t0, t1, n_sub, kla, ec):
+    """One control interval of scheme 1.  n_sub: the RK4 substep count of the fall-back.  Returns (x_end, n) with n = 0 for
+    an interval that fell back."""
+    x = np.array(x, dtype=np.float64)
+    span = t1 - t0
+    v0 = x[0]
+    if ec != 0:
+        f = lambda y: rhs_reaction_w(y, v0, kla, ec)       # noqa: E731   scaled-mass variables, as rk4_reaction_w
+    else:
+        f = lambda y: rhs_reaction(y, 0.0, kla, ec)         # noqa: E731
+    k1 = f(x)
+    n, slaved, fallback, lam0 = b5a_plan(x, k1[8], span, kla)
+    if fallback:
+        if ec != 0:
+            return rk4_reaction_w(x, t0, t1, n_sub, kla, ec), 0
+        return rk4(rhs_reaction, x, t0, t1, n_sub, (kla, ec)), 0
+    h = span / n
+    if slaved:
+        k1[8] = 0.0
+    for s in range(n):
+        if s > 0:
+            k1 = f(x)
+            if slaved:
+                k1[8] = 0.0
+        x = b5_step(f, x, h, k1, slaved)
+    if ec != 0:
+        s_end = x[0] / v0
+        x[1:] = x[1:] / s_end
+    if slaved:
+        x[8] = x[8] / (1.0 + lam0 * span)
+    return x, n
+
+
 def influent_mix(means, stds, rnd):
     """buffer_tank3.py:68-107 for one scenario: series = mean + std*rnd (one rnd vector shared by
     all series), flow-weighted means; returns [0.66, Si..Salk].  means/stds: [14,48], last row = q."""
@@ -202,10 +293,12 @@ class SbrOsRef:
     """One SBROS-v1 environment, restated.  API mirrors SbrOS: reset() -> (obs_DO, obs_EC),
     step(a) -> ((obs_DO, obs_EC), state, reward, done, {})."""
 
-    def __init__(self, tables=None, integrator="lsoda", settle="lsoda"):
+    def __init__(self, tables=None, integrator="lsoda", settle="lsoda", scheme=0):
         self.tables = tables            # (means[8,14,48], stds[8,14,48]) or None if influent is given
         self.integrator = integrator
         self.settle = settle if integrator == "lsoda" else "closed"
+        self.scheme = scheme            # "rk4" mode only: 0 = RK4 x n_sub per interval, 1 = adaptive Butcher-5 (b5a_reaction)
+        self.step_counts = []           # scheme 1: the step count of every reaction interval (0 = fell back to RK4)
 
     # ------------------------------------------------------------------ integrate one span
     def _integrate(self, f, x, t0, t1, n_rows, n_sub, args):
@@ -213,6 +306,10 @@ class SbrOsRef:
             grid = np.linspace(t0, t1, n_rows)
             rows = odeint(f, x, grid, args=args)
             return rows[-1].copy(), rows
+        if f is rhs_reaction and self.scheme == 1:
+            x1, n = b5a_reaction(x, t0, t1, n_sub, *args)
+            self.step_counts.append(n)
+            return x1, None
         if f is rhs_reaction and args[1] != 0:          # a dosing interval: RK4 on the scaled-mass system (rk4_reaction_w)
             return rk4_reaction_w(x, t0, t1, n_sub, *args), None
         return rk4(f, x, t0, t1, n_sub, args), None
