@@ -11,7 +11,7 @@ from . import build as _build
 NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
-ABI_VERSION = 4      # SBR_ABI_VERSION of include/sbr_amd.h; load() refuses a library that reports another
+ABI_VERSION = 5      # SBR_ABI_VERSION of include/sbr_amd.h; load() refuses a library that reports another
 NTRACE = 34          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
 (TR_T, TR_X0, TR_KLA, TR_EC, TR_REWARD, TR_DONE, TR_U_DO, TR_U_EC, TR_E_EC, TR_IE_EC, TR_DCV_EC, TR_R_EQI, TR_R_OCI, TR_R_AE,
  TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST, TR_E_EC_FIRST, TR_IE_EC_FIRST, TR_DCV_EC_FIRST) = (
@@ -37,7 +37,8 @@ class SbrConfig(C.Structure):
         ("t_ratio", C.c_double * 8), ("cyc_Kc", C.c_double), ("cyc_tauI", C.c_double), ("cyc_tauD", C.c_double),
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
-        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32)]
+        ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32),
+        ("scheme", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class SbrError(RuntimeError):
@@ -115,9 +116,17 @@ def load(build_if_missing=True):
                 raise
             continue                   # an A/B variant built from an older source tree may lack newer entry points
         fn.restype, fn.argtypes = res, args
-    if path == _build.LIB and lib.sbr_abi_version() != ABI_VERSION:
-        raise SbrError("libsbr_amd.so reports ABI version %d, this binding was written for %d: rebuild the library "
-                       "(python -c 'import __graft_entry__ as g; g.build()')" % (lib.sbr_abi_version(), ABI_VERSION))
+    # every library is checked, also one selected through SBR_AMD_LIB (the A/B builds of scripts/): a variant built from older
+    # sources would be handed structs and records of another layout.  A library without the symbol counts as a mismatch;
+    # SBR_AMD_ALLOW_ABI_MISMATCH=1 is the explicit way to load one anyway (deliberate old-variant A/Bs).
+    try:
+        reported = int(lib.sbr_abi_version())
+    except AttributeError:
+        reported = None
+    if reported != ABI_VERSION and os.environ.get("SBR_AMD_ALLOW_ABI_MISMATCH") != "1":
+        raise SbrError("%s reports ABI version %s, this binding was written for %d: rebuild the library (python -c 'import "
+                       "__graft_entry__ as g; g.build()'), or set SBR_AMD_ALLOW_ABI_MISMATCH=1 for a deliberate old-variant A/B"
+                       % (os.path.basename(path), reported, ABI_VERSION))
     _lib = lib
     return lib
 

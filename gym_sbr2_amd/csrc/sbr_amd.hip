@@ -524,11 +524,11 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
         "s_load_dword %0, %1, 0x240\n s_load_dword %0, %1, 0x280\n s_load_dword %0, %1, 0x2c0\n s_load_dword %0, %1, 0x300\n"     \
         "s_load_dword %0, %1, 0x340\n s_load_dword %0, %1, 0x380\n s_load_dword %0, %1, 0x3c0\n s_load_dword %0, %1, 0x400\n"     \
         "s_load_dword %0, %1, 0x440\n s_load_dword %0, %1, 0x480\n s_load_dword %0, %1, 0x4c0\n s_load_dword %0, %1, 0x500\n"     \
-        "s_load_dword %0, %1, 0x538\n"
+        "s_load_dword %0, %1, 0x538\n s_load_dword %0, %1, 0x548\n"
 // k_step's argument segment: four pointers / sizes, the flags word (+ padding), four pointers, SbrPar, SbrBuf.  The touched
 // offsets must stay inside it (a scalar load past the segment may fault) and reach its last line.
 static constexpr size_t kStepKernargBytes = 72 + sizeof(SbrPar) + sizeof(SbrBuf);
-static_assert(kStepKernargBytes >= 0x538 + 4 && kStepKernargBytes <= 0x538 + 64,
+static_assert(kStepKernargBytes >= 0x548 + 4 && kStepKernargBytes <= 0x548 + 56,
               "SbrPar / SbrBuf changed size: adjust the offsets of SBR_WARM_LINES to cover k_step's argument segment");
 // In two halves, issue at wave start and wait after the wave's global loads have gone out: the scratch register stays allocated
 // (an in/out operand of the second statement) until the loads have landed, so the compiler cannot hand it to anything else
@@ -768,8 +768,11 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 }
 
 // ------------------------------------------------------------------------------------------- rollout
+#ifndef SBR_ROLLOUT_WAVES
+#define SBR_ROLLOUT_WAVES 2
+#endif
 template <bool OCI>
-__global__ __launch_bounds__(SBR_BLOCK, 2) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
+__global__ __launch_bounds__(SBR_BLOCK, SBR_ROLLOUT_WAVES) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
@@ -1099,7 +1102,8 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.n9_23 = p.n9_2 / p.n9_3; p.inv_n9_3 = 1.0 / p.n9_3;
     for (int k = 0; k < 8; ++k) p.t_ph[k] = c.t_cycle * c.t_ratio[k];
     p.cyc_Kc = c.cyc_Kc; p.cyc_KcI = c.cyc_Kc / c.cyc_tauI; p.cyc_KcD = c.cyc_Kc * c.cyc_tauD; p.cyc_dt = c.cyc_dt;
-    p.substeps = c.substeps; p.terminal = c.terminal;
+    p.substeps = c.substeps; p.terminal = c.terminal; p.scheme = c.scheme;
+    p.inv_Koh = 1.0 / c.Koh; p.inv_Koa = 1.0 / c.Koa;
     p.fill_rows = (int)((c.T_fill - 0) / c.dt);      // int((t_end - t_start)/dt) = 252, :1588
     p.reward_kind = c.reward_kind;
     p.random_scenario = c.random_scenario;
@@ -1186,6 +1190,7 @@ int sbr_default_config(sbr_config* c) {
                                       3.790463057094611};
     memcpy(c->x0, x0, sizeof x0);
     c->substeps = 10; c->out_f64 = 0; c->terminal = 1; c->reward_kind = 0; c->act_f64 = 0; c->random_scenario = 0;
+    c->scheme = 1; c->reserved_ = 0;
     return SBR_OK;
 }
 
@@ -1219,6 +1224,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     const sbr_config& c = e->cfg;
     std::string bad;
     if (c.substeps < 1 || c.substeps > 10000) bad = "substeps out of range";
+    if (c.scheme < 0 || c.scheme > 1) bad = "scheme must be 0 (RK4 x substeps) or 1 (adaptive Butcher-5)";
+    if (!(c.Koa > 0 && c.Koa < 1e300)) bad = "Koa must be positive";
     if (c.reward_kind < 0 || c.reward_kind > 2) bad = "reward_kind must be 0 (EQI/OCI), 1 (G2ANET) or 2 (operating cost)";
     if (!(c.dt > 0) || !(c.t_delta > 0)) bad = "dt and t_delta must be positive";
     else {

@@ -60,6 +60,7 @@ struct SbrPar {
     double cyc_Kc, cyc_KcI, cyc_KcD, cyc_dt;   // positional PID of the per-cycle env (sub_phases_FB.py:205-243)
     // reciprocals of wave-uniform divisors, taken once on the host (an IEEE f64 division is ~19 issue slots on the device)
     double inv_dt, inv_t_delta, inv_substeps, inv_cyc_dt, h_fill;
+    double inv_Koh, inv_Koa;
     double inv_ae_max, inv_ec_max;   // 1 / AE_OCI_max, 1 / EC_OCI_max of module_reward_EQIOCI.py:72, :80 (trajectory export)
     // len(t_range) = int(span/dt) of a control interval (:1339, :1384) is 10 iff span >= rows10_min and 9 iff
     // rows9_min <= span < rows10_min: the smallest doubles whose IEEE quotient by dt reaches 10.0 / 9.0 (found on the
@@ -75,6 +76,7 @@ struct SbrPar {
     double inv_T_fill;
     int32_t cyc_n2[6];
     int32_t substeps, terminal, fill_rows, reward_kind, random_scenario;
+    int32_t scheme;          // 0: RK4 x substeps per control interval; 1: adaptive Butcher-5 (sbr_b5a)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -415,6 +417,132 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cfg.scheme = 1 ("B5A", round 5): a control interval by Butcher's six-stage fifth-order Runge-Kutta scheme with a step count
+// chosen PER LANE from the env's own state, instead of ten RK4 substeps (the CPU oracle's RK4-mode layers under
+// oracle/ - test infrastructure, never linked here - implement the same rule as `b5a_reaction` / `b5a_interval`).
+//   * The only stiff mode of reaction_dxdt (:1658-1787) is the relaxation of dissolved oxygen,
+//         lam(So) = a1 Koh/(Koh+So)^2 + a3 Koa/(Koa+So)^2 + Kla,  a1 = -nu8_1 muH Ss/(Ks+Ss) Xbh,  a3 = -nu8_3 muA Snh/(Knh+Snh) Xba;
+//     every other mode has |lambda| t_delta <= ~1.3, which one or two fifth-order steps resolve far below the parity gate.
+//   * slaved: |So| < 1e-9 and an aeration that could not lift it above that within the interval (the anoxic phases once the
+//     oxygen is used up; the reference's So is 1e-10 ... 1e-52 there): So is HELD during two steps (its slope multiplied by
+//     m_so = 0) and damped afterwards by 1/(1 + lam(0) span);
+//   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span < 0.3 / < 1.0 / else, So_lo = max(0, min(So, So + So' span)): the
+//     lowest So a linear projection reaches (consumption slows as So falls, so it bounds So from below and z from above);
+//   * a four-step lane whose worst case lam(0) span/4 exceeds 3.0 (Butcher-5 is stable on the real axis up to 3.39) is left
+//     to the RK4 substeps (stable to lam dt = 2.78): the function returns true for it and leaves x untouched.
+// The step count is a function of the lane's own state only, and lanes that take fewer steps than their wave-mates are masked
+// out of the later iterations: an env's bits do not depend on which envs share its wavefront (as with the dosing ballot).
+// The steps are written in running-sum form - each stage slope is added to the pending stage bases and the result as soon as
+// it exists (17 vector FMAs per step, at most five 9-vectors live) - with the step-size products h a_ij per lane in VGPRs.
+//   DOSE: the scaled-mass form of sbr_rk4_dose (w = c V/V0; the Monod constants at the five distinct stage times of a step,
+//   the constant source of Ss added to every stage slope); a lane with Q == 0 computes the plain form's values.
+struct SbrB5C { double a21, a31, a42, a51, a54, a61, a62, a63, a65, b1, b3, b4; };
+template <bool DOSE>
+SBR_DEV bool sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, double Q) {
+    const double kla_sat = kla * p.So_sat;
+    const double v0 = x[0], n0 = x[10] - x[9];
+    double a[SBR_NA], k[SBR_NA], xp = x[7], e = 0.0, rs = 1.0;
+    SbrRho o;
+    sbr_gather(x, a);
+    const double rv0 = DOSE ? sbr_rcp(v0) : 0.0;
+    const double qv = Q * rv0;                                   // Q / V0
+    const double srcr = qv * p.EC_conc;                          // the source of w_Ss (a rate)
+    SbrMonod m = sbr_monod(p, kla_sat);                          // at s = 1: the model's own constants
+    // stage 1 of the first step: does not depend on the step size, and its oxygen slope feeds the plan
+    sbr_rates(p, m, a, kla, k, o);
+    if (DOSE) k[A_SS] = k[A_SS] + srcr;
+    k[A_SNO] = k[A_SNO] * p.n9_3;
+    // ---- the plan (oracle: b5a_plan)
+    const double so = a[A_SO];
+    const double proj = __builtin_fma(k[A_SO], span, so);
+    const double lo1 = proj < so ? proj : so;
+    const double so_lo = lo1 > 0.0 ? lo1 : 0.0;
+    const double dh = p.Koh + so_lo, da = p.Koa + so_lo;
+    const double P1 = (p.Ks + a[A_SS]) * (dh * dh), P3 = (p.Knh + a[A_SNH]) * (da * da);
+    const double R = sbr_rcp(P1 * P3);
+    const double r1 = R * P3, r3 = R * P1;                       // 1/((Ks+Ss)(Koh+So_lo)^2), 1/((Knh+Snh)(Koa+So_lo)^2)
+    const double c1 = (-p.n8_1 * p.muH) * (a[A_SS] * a[A_XBH]), c3 = (-p.n8_3 * p.muA) * (a[A_SNH] * a[A_XBA]);
+    const double z_ub = __builtin_fma(c1 * p.Koh, r1, __builtin_fma(c3 * p.Koa, r3, kla)) * span;
+    const double lam0 = __builtin_fma(c1 * p.inv_Koh, r1 * (dh * dh), __builtin_fma(c3 * p.inv_Koa, r3 * (da * da), kla));
+    const bool slaved = (fabs(so) < 1e-9) && (kla_sat * span < 1e-9);
+    int n = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : 4));
+    const bool fallback = !slaved && n == 4 && (lam0 * span * 0.25 > 3.0);
+    if (fallback) n = 0;
+    const double m_so = slaved ? 0.0 : 1.0;
+    const double h = span * (n == 1 ? 1.0 : (n == 2 ? 0.5 : 0.25));
+    k[A_SO] = k[A_SO] * m_so;
+    SbrB5C c;
+    c.a21 = h * 0.25; c.a31 = h * 0.125; c.a42 = h * -0.5; c.a51 = h * (3.0 / 16.0); c.a54 = h * (9.0 / 16.0);
+    c.a61 = h * (-3.0 / 7.0); c.a62 = h * (2.0 / 7.0); c.a63 = h * (12.0 / 7.0); c.a65 = h * (8.0 / 7.0);
+    c.b1 = h * (7.0 / 90.0); c.b3 = h * (32.0 / 90.0); c.b4 = h * (12.0 / 90.0);
+    const double dl = DOSE ? h * qv : 0.0;                       // growth of s = V/V0 per step
+    // one stage: slopes of y at scaled-mass time e_st
+    auto stage = [&](const double (&y)[SBR_NA], double e_st) {
+        if (DOSE) { const SbrScaled cs = sbr_scale_consts(p, kla_sat, e_st); m = cs.m; rs = cs.rs; }
+        sbr_rates(p, m, y, kla, k, o);
+        if (DOSE) k[A_SS] = k[A_SS] + srcr;
+        k[A_SNO] = k[A_SNO] * p.n9_3;
+        k[A_SO] = k[A_SO] * m_so;
+    };
+#pragma unroll 1
+    for (int s = 0; s < n; ++s) {
+        // running-sum form, each sum formed as late as its terms allow: at most a, k1 and three pending vectors live
+        double k1[SBR_NA], y[SBR_NA], p4[SBR_NA], p5[SBR_NA], p6[SBR_NA], pb[SBR_NA];
+        if (s > 0) stage(a, e);                                  // stage 1 (the first step's is above)
+        double xq = c.b1 * o.s45b;                               // sum_j h b_j (rho4 + rho5)_j / bH: Xp' = nu7 bH s45b
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) { k1[i] = k[i]; y[i] = __builtin_fma(c.a21, k[i], a[i]); }
+        stage(y, __builtin_fma(0.25, dl, e));                    // stage 2 at t + h/4
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            y[i] = __builtin_fma(c.a31, k[i], __builtin_fma(c.a31, k1[i], a[i]));
+            p4[i] = __builtin_fma(c.a42, k[i], a[i]);
+            p6[i] = __builtin_fma(c.a62, k[i], __builtin_fma(c.a61, k1[i], a[i]));
+        }
+        stage(y, __builtin_fma(0.25, dl, e));                    // stage 3 at t + h/4
+        xq = __builtin_fma(c.b3, o.s45b, xq);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            y[i] = __builtin_fma(h, k[i], p4[i]); p6[i] = __builtin_fma(c.a63, k[i], p6[i]);
+            pb[i] = __builtin_fma(c.b3, k[i], __builtin_fma(c.b1, k1[i], a[i]));
+            p5[i] = __builtin_fma(c.a51, k1[i], a[i]);
+        }
+        stage(y, __builtin_fma(0.5, dl, e));                     // stage 4 at t + h/2
+        xq = __builtin_fma(c.b4, o.s45b, xq);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) {
+            y[i] = __builtin_fma(c.a54, k[i], p5[i]); p6[i] = __builtin_fma(-c.a63, k[i], p6[i]); pb[i] = __builtin_fma(c.b4, k[i], pb[i]);
+        }
+        stage(y, __builtin_fma(0.75, dl, e));                    // stage 5 at t + 3h/4
+        xq = __builtin_fma(c.b3, o.s45b, xq);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) { y[i] = __builtin_fma(c.a65, k[i], p6[i]); pb[i] = __builtin_fma(c.b3, k[i], pb[i]); }
+        e = e + dl;
+        stage(y, e);                                             // stage 6 at t + h: its constants are the next step's stage-1 constants
+        xp = __builtin_fma(p.n7_45b, __builtin_fma(c.b1, o.s45b, xq), xp);
+#pragma unroll
+        for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(c.b1, k[i], pb[i]);
+    }
+    if (!fallback) {
+        const double c14 = 1.0 / 14.0;
+        if (DOSE) {
+            // back to concentrations: c = w / s_end (rs = 1/s at the last stage time = s_end); Si, Xi and the charge balance only dilute
+#pragma unroll
+            for (int i = 0; i < SBR_NA; ++i) a[i] = a[i] * rs;
+            xp = xp * rs;
+            x[0] = __builtin_fma(v0, e, v0);
+            x[1] = x[1] * rs; x[3] = x[3] * rs;
+        }
+        a[A_SO] = slaved ? a[A_SO] * sbr_rcp(__builtin_fma(lam0, span, 1.0)) : a[A_SO];
+        const double u = DOSE ? __builtin_fma(-n0, c14, x[13]) * rs : __builtin_fma(-n0, c14, x[13]);
+        sbr_scatter(a, x);
+        x[7] = xp;
+        x[13] = __builtin_fma(x[10] - x[9], c14, u);
+    }
+    return fallback;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Per-env controller registers that are live ACROSS the RK4 loop - kept small on purpose.  The Kla history and
 // the bookkeeping rows (return, steps, status) are not needed until after the integration: the step kernel loads them
 // up front with everything else (one exposed round trip) and parks them in LDS, so the hot loop keeps its VGPRs.
@@ -529,8 +657,19 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
     const double h = span * p.inv_substeps;
-    if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<0>(p, x, h, p.substeps, kla, 0.0, nold);
-    else sbr_rk4<1>(p, x, h, p.substeps, kla, ec, nold);
+    bool rk4 = true;                                   // per lane: the RK4 substeps integrate this interval
+    if (p.scheme == 1) {                               // wave-uniform
+#ifdef SBR_B5_ONE_FORM
+        rk4 = sbr_b5a<true>(p, x, span, kla, ec);
+#else
+        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) rk4 = sbr_b5a<false>(p, x, span, kla, 0.0);
+        else rk4 = sbr_b5a<true>(p, x, span, kla, ec);
+#endif
+    }
+    if (rk4) {                                         // scheme 0: every lane; scheme 1: the lanes behind the stability guard
+        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<0>(p, x, h, p.substeps, kla, 0.0, nold);
+        else sbr_rk4<1>(p, x, h, p.substeps, kla, ec, nold);
+    }
     if (c.n_new == 0) c.knew[0] = kla; else c.knew[1] = kla;      // n_new <= 2, see SbrCtl
     c.n_new += 1;
     c.kla_last = kla;

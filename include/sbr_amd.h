@@ -116,6 +116,15 @@ typedef struct sbr_config {
                                   per env and reset on the device, uniformly, as SbrEnv4.reset does with
                                   np.random.choice(8, 1) (gym_SBR_env4.py:107): Philox4x32-10 keyed by `seed`, stream 2,
                                   subsequence = GLOBAL env id (sbr_draw_scenarios returns the same draw) */
+    int32_t scheme;            /* how sbr_step / sbr_rollout integrate a control interval of reaction_dxdt (:1658-1787, odeint call
+                                  sites :1953, :2041).  0: `substeps` classical RK4 substeps (40 right-hand-side evaluations).
+                                  1 (default, round 5): Butcher's fifth-order scheme with 1, 2 or 4 steps chosen per env and
+                                  interval from the env's own state - dissolved oxygen, the system's one stiff mode, is held
+                                  where it is slaved to zero, and an env whose oxygen mode would be unstable at four steps
+                                  falls back to the RK4 substeps: ~10 evaluations per interval, and closer to
+                                  the reference's trajectories than scheme 0 (closed loop, worst 0.36 of the 1e-5 gate against
+                                  0.51).  The fill phase, the idle phase and SBR-v2 use RK4 under either scheme. */
+    int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; must be 0 */
 } sbr_config;
 
 typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for N envs on one GPU */
@@ -124,8 +133,8 @@ typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for
 const char* sbr_version(void);
 /* Bumped whenever a signature, a struct layout or a record width of this header changes.  A consumer compiled against this
  * header checks sbr_abi_version() == SBR_ABI_VERSION once after loading the library (round 4 = 4: sbr_set_trace takes the
- * record width, SBR_NTRACE = 34). */
-#define SBR_ABI_VERSION 4
+ * record width, SBR_NTRACE = 34; round 5 = 5: sbr_config.scheme). */
+#define SBR_ABI_VERSION 5
 int sbr_abi_version(void);
 int sbr_default_config(sbr_config* cfg);
 int sbr_device_count(void);          /* HIP devices visible; 0 if none (never throws) */

@@ -35,7 +35,7 @@ typedef struct {
     double x0[NX];
     int32_t substeps, out_f64, terminal, reward_kind, act_f64, random_scenario;
     int32_t scheme;                 /* 0: RK4 x substeps per control interval; 1: adaptive Butcher-5 (b5a_interval) */
-    int32_t pad_;
+    int32_t reserved_;
 } sbro_params;
 
 /* one environment; field order is part of the ctypes contract in oracle/sbr_oracle.py */
@@ -89,7 +89,7 @@ void sbro_default_params(sbro_params* p) {
                                   3.790463057094611};
     memcpy(p->x0, x0, sizeof x0);
     p->substeps = 10; p->out_f64 = 1; p->terminal = 1; p->reward_kind = 0; p->act_f64 = 0; p->random_scenario = 0;
-    p->scheme = 0; p->pad_ = 0;
+    p->scheme = 1; p->reserved_ = 0;          /* the product's default (sbr_default_config) */
 }
 
 int sbro_sizeof_env(void) { return (int)sizeof(sbro_env); }

@@ -23,7 +23,7 @@ class Params(C.Structure):
         ("cyc_dt", C.c_double),
         ("x0", C.c_double * NX), ("substeps", C.c_int32), ("out_f64", C.c_int32),
         ("terminal", C.c_int32), ("reward_kind", C.c_int32), ("act_f64", C.c_int32), ("random_scenario", C.c_int32),
-        ("scheme", C.c_int32), ("pad_", C.c_int32)]
+        ("scheme", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Env(C.Structure):
@@ -99,9 +99,13 @@ def lib():
     return _lib
 
 
-def default_params():
+def default_params(scheme=None):
+    """The reference's constants; scheme as the product's sbr_default_config() (1 = adaptive Butcher-5) unless given
+    (0 = RK4 x substeps)."""
     p = Params()
     lib().sbro_default_params(C.byref(p))
+    if scheme is not None:
+        p.scheme = int(scheme)
     return p
 
 
@@ -224,7 +228,7 @@ def eval_rhs(kind, x, kla, ec, loading=None, params=None):
 
 
 def rk4(kind, x, span, n, kla, ec=0.0, loading=None, params=None):
-    p = params if params is not None else default_params()
+    p = params if params is not None else default_params(scheme=0)
     x = np.array(x, dtype=np.float64)
     ld = None if loading is None else np.ascontiguousarray(loading, dtype=np.float64)
     lib().sbro_rk4(C.byref(p), C.c_int(kind), _p(x), C.c_double(span), C.c_int(n), C.c_double(kla), C.c_double(ec),

@@ -293,7 +293,7 @@ class SbrOsRef:
     """One SBROS-v1 environment, restated.  API mirrors SbrOS: reset() -> (obs_DO, obs_EC),
     step(a) -> ((obs_DO, obs_EC), state, reward, done, {})."""
 
-    def __init__(self, tables=None, integrator="lsoda", settle="lsoda", scheme=0):
+    def __init__(self, tables=None, integrator="lsoda", settle="lsoda", scheme=1):
         self.tables = tables            # (means[8,14,48], stds[8,14,48]) or None if influent is given
         self.integrator = integrator
         self.settle = settle if integrator == "lsoda" else "closed"

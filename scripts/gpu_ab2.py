@@ -6,7 +6,8 @@ two rounds, HIP events on the launch stream, bench.py's workload (physical polic
 Under bench.py's random NO3 set-points hardly any lane doses after the first ten calls of an episode (the PID's output is
 clamped at 0), so "dosing" then mostly times the closed-reactor loop; AB_POLICY=dose sets the NO3 set-point to 0, which makes
 every lane dose in the anoxic phases (the reference's own anchor episode, constant action [2, 5], doses in most of them too).
-usage: [AB_POLICY=dose] python scripts/gpu_ab2.py name1 name2 ... [-- N1 N2 ...]      (name "tree" = the in-tree library)"""
+AB_SCHEME=0 / 1 selects cfg.scheme (round 5).
+usage: [AB_POLICY=dose] [AB_SCHEME=0] python scripts/gpu_ab2.py name1 name2 ... [-- N1 N2 ...]      (name "tree" = the in-tree library)"""
 import os
 import subprocess
 import sys
@@ -16,10 +17,13 @@ CHILD = r'''
 import os, sys, time
 sys.path.insert(0, %r)
 import torch
-from gym_sbr2_amd import SbrOSVec
+from gym_sbr2_amd import SbrOSVec, _capi
 out = []
+cfg = _capi.default_config()
+if os.environ.get("AB_SCHEME"):                    # 0 = RK4 x substeps, 1 = adaptive Butcher-5 (the default)
+    cfg.scheme = int(os.environ["AB_SCHEME"])
 for N in %r:
-    env = SbrOSVec(N)
+    env = SbrOSVec(N, config=cfg)
     gid = torch.arange(N, device="cuda")
     scen = (4 + gid %% 4).to(torch.int32)
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234)

@@ -21,8 +21,11 @@ sizes = [int(v) for v in sys.argv[1:]] or [65536, 4096]
 lib = _capi.load()
 lib.sbr_set_stamps.restype = C.c_int
 lib.sbr_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
+cfg = _capi.default_config()
+if os.environ.get("AB_SCHEME"):                    # 0 = RK4 x substeps, 1 = adaptive Butcher-5 (the default)
+    cfg.scheme = int(os.environ["AB_SCHEME"])
 for N in sizes:
-    env = SbrOSVec(N)
+    env = SbrOSVec(N, config=cfg)
     scen = (torch.arange(N, device="cuda") % 8).to(torch.int32)
     a = torch.rand(N, 2, device="cuda") * torch.tensor([8.0, 15.0], device="cuda")
     if os.environ.get("SBR_TL_POLICY") == "dose":      # NO3 set-point 0: every lane doses carbon in the anoxic phases

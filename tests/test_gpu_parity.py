@@ -163,7 +163,11 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
         if c < ncall - 1:
             worst_gold = np.maximum(worst_gold, [gate(x[i], E[i]["step_x_end"][c]).max() for i in range(n)])
             worst_tight = np.maximum(worst_tight, [gate(x[i], T[i]["step_x_end"][c]).max() for i in range(n)])
-            assert np.abs(_np(r) - [t["step_reward"][c] for t in T]).max() < 5e-7       # rewards, all six episodes
+            # rewards, all six episodes.  `zeros` (index 3) gets 5e-6: its NO3-PID output is unsaturated for long stretches, where
+            # EC carries Kc = 100 times the deviation of Sno (a third of a gate = 7e-5 moves EC by 14 % of its range) into the
+            # cost term of the reward (measured: 2.0e-6 under scheme 1, 3e-7 under scheme 0; every other episode < 4e-10)
+            dr = np.abs(_np(r) - [t["step_reward"][c] for t in T])
+            assert np.delete(dr, 3).max() < 5e-7 and dr[3] < 5e-6
             for i, e in enumerate(E):      # rewards / observations against the reference itself
                 if EPISODES[i] in CLOSED_LOOP_OK:
                     # reward = (1 - S)/473 with S = EQI2^2 + OCI^2 <= ~5: a 1e-5 state error gives <= 2e-5*S/473 ~ 2e-7
@@ -1158,8 +1162,12 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
     ends = lo + np.cumsum(rows - 1)[np.searchsorted(e["iv_call"], np.arange(463), side="right") - 1] - 1
     rel = np.abs(d["x_t"][ends[:462]] - per_call["x_t"][:462]) / (np.abs(per_call["x_t"][:462]) + 1e-9)
     assert rel.max() < 1e-12, rel.max()
-    rel = np.abs(d["x_t"][-1] - per_call["x_t"][462]) / (np.abs(per_call["x_t"][462]) + 1e-9)      # ... and of the done call, after idle
-    assert rel.max() < 1e-9, rel.max()
+    # ... and of the done call, after idle: its rows are replayed from the START of the call's last interval with RK4 nodes
+    # (sbr_eval_substeps), while step() integrated that interval with the handle's scheme; under scheme 1 the two end states
+    # differ by the two discretisations' distance (~1e-2 of the gate: 3e-7 .. 3e-6 relative after the idle phase; 1e-9 with
+    # cfg.scheme = 0, where the replay repeats the step's own arithmetic)
+    rel = np.abs(d["x_t"][-1] - per_call["x_t"][462]) / (np.abs(per_call["x_t"][462]) + 1e-9)
+    assert rel.max() < 2e-5 and gate(d["x_t"][-1], per_call["x_t"][462]).max() < 0.1, rel.max()
     # a running episode: dense rows exist from the first call on
     env2 = G.make("SBROS-v1")
     env2.reset(rnd=e["rnd"])
@@ -1283,8 +1291,8 @@ def test_other_substep_counts_against_oracle(G, tables, substeps):
     means, stds = tables
     n, calls = 192, 90
     scen = (np.arange(n) % 8).astype(np.int32)
-    cfg = _capi.default_config(); cfg.substeps = substeps
-    p = O.default_params(); p.substeps = substeps
+    cfg = _capi.default_config(); cfg.substeps = substeps; cfg.scheme = 0
+    p = O.default_params(scheme=0); p.substeps = substeps
     env = G.SbrOSVec(n, out_dtype=torch.float64, action_dtype=torch.float64, config=cfg)
     ora = O.OracleBatch(n, params=p)
     rnd = np.random.RandomState(substeps).randn(n, 48)
@@ -1703,7 +1711,7 @@ def test_trace_record_width_and_abi_version(G):
     import ctypes as C
     from gym_sbr2_amd import _capi
     lib = _capi.load()
-    assert lib.sbr_abi_version() == _capi.ABI_VERSION == 4 and _capi.NTRACE == 34
+    assert lib.sbr_abi_version() == _capi.ABI_VERSION == 5 and _capi.NTRACE == 34
     env = G.SbrOSVec(8)
     buf = torch.zeros(4, _capi.NTRACE, 8, dtype=torch.float64, device="cuda")
     assert lib.sbr_set_trace(env._h, buf.data_ptr(), 8, 4, 31) == -1 and b"record_width" in lib.sbr_last_error(env._h)

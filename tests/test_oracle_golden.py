@@ -164,9 +164,9 @@ def test_pid_known_answers_open_loop(name, tables):
     the previous-Kla bias and the phase-boundary double steps."""
     e = golden("sbros_" + name)
     n = int(e["n_calls"])
-    py = R.SbrOsRef(tables, integrator="rk4")
+    py = R.SbrOsRef(tables, integrator="rk4", scheme=0)
     py.reset(rnd=e["rnd"], scenario=_scn(e))
-    b = O.OracleBatch(1)
+    b = O.OracleBatch(1, O.default_params(scheme=0))
     b.reset(e["influent_mixed"][None])
     checked = clamped_hi = clamped_lo = doubles = 0
     for k in range(1, n):
@@ -214,11 +214,12 @@ def test_pid_known_answers_open_loop(name, tables):
 
 @pytest.mark.parametrize("name", ALL_EPISODES)
 def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(name, tables):
+    """Scheme 0 (RK4 x 10 per interval); scheme 1 has its own test below."""
     means, stds = tables
     e = golden("sbros_" + name)
-    b = O.OracleBatch(1)
+    b = O.OracleBatch(1, O.default_params(scheme=0))
     cobs = b.reset(b.mix(means, stds, [_scn(e)], e["rnd"][None]))
-    py = R.SbrOsRef(tables, integrator="rk4")
+    py = R.SbrOsRef(tables, integrator="rk4", scheme=0)
     pobs = py.reset(rnd=e["rnd"], scenario=_scn(e))
     assert np.array_equal(cobs[0], np.r_[pobs[0], pobs[1]]) and np.array_equal(b.envs["x"][0], py.x)
     n = int(e["n_calls"])
@@ -255,9 +256,9 @@ def test_rk4_open_loop_every_interval_inside_gate(name):
         assert nv == 463 and int(e["domain_exit_call"]) == -1      # the bench's workload stays inside the model's domain
 
 
-def _c_episode(e, tables):
+def _c_episode(e, tables, scheme=0):
     means, stds = tables
-    b = O.OracleBatch(1)
+    b = O.OracleBatch(1, O.default_params(scheme=scheme))
     b.reset(b.mix(means, stds, [_scn(e)], e["rnd"][None]))
     xs = []
     for k in range(int(e["n_calls"])):
@@ -345,7 +346,7 @@ def test_control_rounding_noise_is_amplified_to_gate_level_by_the_closed_loop(ta
     means, stds = tables
     n, ncall = 1024, 463
     scen = (np.arange(n) % 8).astype(np.int32)
-    strict = O.OracleBatch(n, nthreads=4)
+    strict = O.OracleBatch(n, O.default_params(scheme=0), nthreads=4)
     infl = strict.mix(means, stds, scen, np.zeros((n, 48)))
     rs = np.random.RandomState(2)
     acts = [np.column_stack([rs.uniform(0, 8, n), rs.uniform(0, 15, n)]).astype(np.float32).astype(np.float64)
@@ -354,7 +355,7 @@ def test_control_rounding_noise_is_amplified_to_gate_level_by_the_closed_loop(ta
     for variant in ("", "_fma"):
         prev = O.use_variant(variant)
         try:
-            b = O.OracleBatch(n, nthreads=4)
+            b = O.OracleBatch(n, O.default_params(scheme=0), nthreads=4)
             b.reset(infl)
             xs, dones = [], []
             for c in range(ncall - 1):
@@ -468,9 +469,7 @@ def test_substep_count_is_set_by_accuracy_and_stability():
 # (oracle/sbr_ref.py b5a_*, oracle/sbr_oracle.c b5a_interval) instead of ten RK4 substeps.  The same bars as
 # scheme 0, on the same reference fixtures.
 def _scheme1_params():
-    p = O.default_params()
-    p.scheme = 1
-    return p
+    return O.default_params(scheme=1)
 
 
 @pytest.mark.parametrize("name", ["const_2_5", "random_b", "zeros", "scn0_c25", "scn4_phys", "scn5_c25", "scn7_phys"])
@@ -553,4 +552,5 @@ def test_scheme1_falls_back_to_rk4_where_butcher5_would_be_unstable():
     x0[5] *= 3.0; x0[6] *= 3.0
     x2, n2 = O.reaction_interval(x0, span, kla, 0.0)
     assert n2 == 0 and np.array_equal(x2, O.rk4(0, x0, span, 10, kla, 0.0))
+    assert O.reaction_interval(x0, span, kla, 0.0, scheme=0)[1] == -1
     assert np.isfinite(x2).all()
