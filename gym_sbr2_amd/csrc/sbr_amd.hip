@@ -579,8 +579,11 @@ struct SbrTraceRec {
     }
 };
 
-template <typename OutT, typename ActT, int BLK, bool OCI>
-__global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
+#ifndef SBR_STEP_MIN_BLOCKS
+#define SBR_STEP_MIN_BLOCKS 1      // A/B builds: 2 caps k_step<.., 256, ..> at 256 registers (two waves per SIMD)
+#endif
+template <typename OutT, typename ActT, int BLK, bool OCI, int SCH>
+__global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
                                                       const ActT* __restrict__ action, uint32_t flags, OutT* __restrict__ obs,
                                                       OutT* __restrict__ state, OutT* __restrict__ reward,
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
@@ -660,12 +663,12 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 #ifndef SBR_STEP_LOOP
 #define SBR_STEP_LOOP false     // straight-line: the second interval of a phase-boundary call out of line (247 VGPRs; the loop form needs 278 with the dependent ring loads live across the integration)
 #endif
-        sbr_run_intervals<SBR_STEP_LOOP>(p, c, x, a0, a1, x6, tr);
+        sbr_run_intervals<SBR_STEP_LOOP, SCH>(p, c, x, a0, a1, x6, tr);
         SBR_STAMP(3, false);                  // PIDs + RK4 done
         SbrHistInc hs{my[SBR_PK_W8 * 64], kla_before, {lv[0], lv[1], lv[2]}, 0.0, false};
         x6.get(xa6);
         double ksum = OCI ? my[SBR_PK_KSUM * 64] : 0.0;
-        r = sbr_finish_step<OCI>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
+        r = sbr_finish_step<OCI, SCH>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         // everything that reads the three ring entries loaded before the integration comes BEFORE the first store: the memory
         // counter retires in order, so a wait for one of those (long finished) loads placed after the plant stores would wait
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(BLK) void k_step(double* __restrict__ bx, double* _
 #ifndef SBR_ROLLOUT_WAVES
 #define SBR_ROLLOUT_WAVES 2
 #endif
-template <bool OCI>
+template <bool OCI, int SCH>
 __global__ __launch_bounds__(SBR_BLOCK, SBR_ROLLOUT_WAVES) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
     const uint32_t l = threadIdx.x;
@@ -803,17 +806,17 @@ __global__ __launch_bounds__(SBR_BLOCK, SBR_ROLLOUT_WAVES) void k_rollout(SbrPar
         if (finished) continue;
         double t_obs;
         bool dn;
-        sbr_run_intervals<false>(p, c, x, (double)a0, (double)a1, x6, SbrNoTrace{});
+        sbr_run_intervals<false, SCH>(p, c, x, (double)a0, (double)a1, x6, SbrNoTrace{});
         x6.get(xa6);
         SbrHistReg hs{hist};
-        const double r = sbr_finish_step<OCI, SbrHistReg, false>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
+        const double r = sbr_finish_step<OCI, SCH, SbrHistReg, false>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
         acc += r; ret += r; status |= c.st_new;
         if (steps < SBR_MAX_STEPS) steps += 1;
         if (dn) { finished = true; terminal_due = !OCI && p.terminal; }
     }
     if (terminal_due) {               // a finished lane skipped every later call, so c, x and hist are as the done call left them
         SbrHistReg hs{hist};
-        qw = sbr_terminal(p, c, hs, x);
+        qw = sbr_terminal<SCH>(p, c, hs, x);
     }
     store_x(b, i0, l, x);
     store_ctl(b, i0, l, c);
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
 }
 
 // SbrEnv2.step: one whole 12 h cycle per env (528 control intervals x 10 RK4 substeps) in one launch.
-template <typename OutT, typename ActT>
+template <typename OutT, typename ActT, int SCH>
 __global__ __launch_bounds__(SBR_BLOCK, 2) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {
     const uint32_t l = threadIdx.x;
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(SBR_BLOCK, 2) void k_cycle(SbrPar p, SbrBuf b, cons
     for (int j = 0; j < SBR_NX; ++j) ld[j] = INFL(j);
     ld[0] = (p.WV - x[0]) * p.inv_t_ph0;                              // Qin / (t_cycle * t_ratio[0]), gym_SBR_env2.py:144 (host reciprocal: 1 ulp)
     const int st0 = sbr_status_bits(p, x);
-    const double r = sbr_cycle_env(p, x, ld, (double)action[3 * i], (double)action[3 * i + 1], (double)action[3 * i + 2], o3,
+    const double r = sbr_cycle_env<SCH>(p, x, ld, (double)action[3 * i], (double)action[3 * i + 1], (double)action[3 * i + 2], o3,
                                    diag ? diag + i * SBR_NCYC_DIAG : nullptr, 1);
     store_x(b, i0, l, x);
     CTRL(R_RET) = CTRL(R_RET) + r; CTRL(R_T) = p.t_cycle;
@@ -1141,15 +1144,15 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
 #ifndef SBR_SMALL_BATCH
 #define SBR_SMALL_BATCH 49152       // up to this many envs k_step runs in 64-thread workgroups (measured: profiles/r02_ab_block.log)
 #endif
-template <typename OutT, typename ActT, bool OCI>
+template <typename OutT, typename ActT, bool OCI, int SCH>
 static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                           hipStream_t st) {
     const uint32_t flags = (e->par.KcD_DO != 0.0 || e->par.KcD_EC != 0.0 || e->buf.trace != nullptr) ? SBR_KF_NEED_M2 : 0u;
     if (e->n <= SBR_SMALL_BATCH)
-        hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
+        hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI, SCH>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
                            e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
-        hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
+        hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI, SCH>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
                            e->buf.ctrl, e->buf.n, (const ActT*)action,
                            flags | ((e->n >= SBR_STAGGER_MIN_ENVS && e->n <= SBR_STAGGER_MAX_ENVS) ? SBR_KF_STAGGER : 0u), (OutT*)obs,
                            (OutT*)state, (OutT*)reward, done, e->par, e->buf);
@@ -1157,13 +1160,14 @@ static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state
 template <typename OutT, typename ActT>
 static void launch_step(sbr_env* e, const void* action, void* obs, void* state, void* reward, uint8_t* done,
                         hipStream_t st) {
-    if (e->cfg.reward_kind == 2) launch_step_k<OutT, ActT, true>(e, action, obs, state, reward, done, st);
-    else launch_step_k<OutT, ActT, false>(e, action, obs, state, reward, done, st);
+    const bool oci = e->cfg.reward_kind == 2, b5 = e->cfg.scheme == 1;      // one instantiation per reward family and scheme
+    if (oci) { if (b5) launch_step_k<OutT, ActT, true, 1>(e, action, obs, state, reward, done, st); else launch_step_k<OutT, ActT, true, 0>(e, action, obs, state, reward, done, st); }
+    else { if (b5) launch_step_k<OutT, ActT, false, 1>(e, action, obs, state, reward, done, st); else launch_step_k<OutT, ActT, false, 0>(e, action, obs, state, reward, done, st); }
 }
 
 extern "C" {
 
-const char* sbr_version(void) { return "sbr_amd 0.4.0 (gfx950, fp64 RK4)"; }
+const char* sbr_version(void) { return "sbr_amd 0.5.0 (gfx950, fp64; scheme 1 = adaptive Butcher-5, scheme 0 = RK4)"; }
 int sbr_abi_version(void) { return SBR_ABI_VERSION; }
 
 int sbr_default_config(sbr_config* c) {
@@ -1400,7 +1404,8 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
-#define CSTEP(T, A) hipLaunchKernelGGL((k_cycle<T, A>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
+#define CSTEP(T, A) do { if (e->cfg.scheme == 1) hipLaunchKernelGGL((k_cycle<T, A, 1>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag); \
+                         else hipLaunchKernelGGL((k_cycle<T, A, 0>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag); } while (0)
     if (e->cfg.out_f64) { if (e->cfg.act_f64) CSTEP(double, double); else CSTEP(double, float); }
     else { if (e->cfg.act_f64) CSTEP(float, double); else CSTEP(float, float); }
 #undef CSTEP
@@ -1411,12 +1416,11 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
 int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
     if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
     ON_DEVICE(e);
-    if (e->cfg.reward_kind == 2)
-        hipLaunchKernelGGL(k_rollout<true>, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
-                           policy_seed, returns, actions_out);
-    else
-        hipLaunchKernelGGL(k_rollout<false>, grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps,
-                           policy_seed, returns, actions_out);
+#define ROLL(O, S) hipLaunchKernelGGL((k_rollout<O, S>), grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps, \
+                                      policy_seed, returns, actions_out)
+    if (e->cfg.reward_kind == 2) { if (e->cfg.scheme == 1) ROLL(true, 1); else ROLL(true, 0); }
+    else { if (e->cfg.scheme == 1) ROLL(false, 1); else ROLL(false, 0); }
+#undef ROLL
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

@@ -428,8 +428,8 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 //     m_so = 0) and damped afterwards by 1/(1 + lam(0) span);
 //   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span < 0.3 / < 1.0 / else, So_lo = max(0, min(So, So + So' span)): the
 //     lowest So a linear projection reaches (consumption slows as So falls, so it bounds So from below and z from above);
-//   * a four-step lane whose worst case lam(0) span/4 exceeds 3.0 (Butcher-5 is stable on the real axis up to 3.39) is left
-//     to the RK4 substeps (stable to lam dt = 2.78): the function returns true for it and leaves x untouched.
+//   * in the last case (the knee, So moving through Koh) n = max(4, floor(lam(0) span / 3) + 1): the worst-case lam(0) h stays
+//     below 3.0 (Butcher-5 is stable on the real axis up to 3.39); the reference plant never needs more than four steps.
 // The step count is a function of the lane's own state only, and lanes that take fewer steps than their wave-mates are masked
 // out of the later iterations: an env's bits do not depend on which envs share its wavefront (as with the dosing ballot).
 // The steps are written in running-sum form - each stage slope is added to the pending stage bases and the result as soon as
@@ -438,7 +438,7 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 //   the constant source of Ss added to every stage slope); a lane with Q == 0 computes the plain form's values.
 struct SbrB5C { double a21, a31, a42, a51, a54, a61, a62, a63, a65, b1, b3, b4; };
 template <bool DOSE>
-SBR_DEV bool sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, double Q) {
+SBR_DEV void sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, double Q) {
     const double kla_sat = kla * p.So_sat;
     const double v0 = x[0], n0 = x[10] - x[9];
     double a[SBR_NA], k[SBR_NA], xp = x[7], e = 0.0, rs = 1.0;
@@ -465,11 +465,13 @@ SBR_DEV bool sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double k
     const double z_ub = __builtin_fma(c1 * p.Koh, r1, __builtin_fma(c3 * p.Koa, r3, kla)) * span;
     const double lam0 = __builtin_fma(c1 * p.inv_Koh, r1 * (dh * dh), __builtin_fma(c3 * p.inv_Koa, r3 * (da * da), kla));
     const bool slaved = (fabs(so) < 1e-9) && (kla_sat * span < 1e-9);
-    int n = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : 4));
-    const bool fallback = !slaved && n == 4 && (lam0 * span * 0.25 > 3.0);
-    if (fallback) n = 0;
+    // n = 2 (slaved) / 1 / 2 / the knee: max(4, floor(lam(0) span / 3) + 1), capped at 64 so that every wave terminates
+    const double qn = lam0 * span * (1.0 / 3.0);
+    const int n_knee = qn < 4.0 ? 4 : (!(qn < 64.0) ? 64 : (int)qn + 1);
+    const int n = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : n_knee));
     const double m_so = slaved ? 0.0 : 1.0;
-    const double h = span * (n == 1 ? 1.0 : (n == 2 ? 0.5 : 0.25));
+    // span / n: exact for 1, 2 and 4 (every step count of the reference plant); one reciprocal for the rest
+    const double h = n == 1 ? span : (n == 2 ? span * 0.5 : (n == 4 ? span * 0.25 : span * sbr_rcp((double)n)));
     k[A_SO] = k[A_SO] * m_so;
     SbrB5C c;
     c.a21 = h * 0.25; c.a31 = h * 0.125; c.a42 = h * -0.5; c.a51 = h * (3.0 / 16.0); c.a54 = h * (9.0 / 16.0);
@@ -523,23 +525,26 @@ SBR_DEV bool sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double k
 #pragma unroll
         for (int i = 0; i < SBR_NA; ++i) a[i] = __builtin_fma(c.b1, k[i], pb[i]);
     }
-    if (!fallback) {
-        const double c14 = 1.0 / 14.0;
-        if (DOSE) {
-            // back to concentrations: c = w / s_end (rs = 1/s at the last stage time = s_end); Si, Xi and the charge balance only dilute
+    const double c14 = 1.0 / 14.0;
+    if (DOSE) {
+        // back to concentrations: c = w / s_end (rs = 1/s at the last stage time = s_end); Si, Xi and the charge balance only dilute
 #pragma unroll
-            for (int i = 0; i < SBR_NA; ++i) a[i] = a[i] * rs;
-            xp = xp * rs;
-            x[0] = __builtin_fma(v0, e, v0);
-            x[1] = x[1] * rs; x[3] = x[3] * rs;
-        }
-        a[A_SO] = slaved ? a[A_SO] * sbr_rcp(__builtin_fma(lam0, span, 1.0)) : a[A_SO];
-        const double u = DOSE ? __builtin_fma(-n0, c14, x[13]) * rs : __builtin_fma(-n0, c14, x[13]);
-        sbr_scatter(a, x);
-        x[7] = xp;
-        x[13] = __builtin_fma(x[10] - x[9], c14, u);
+        for (int i = 0; i < SBR_NA; ++i) a[i] = a[i] * rs;
+        xp = xp * rs;
+        x[0] = __builtin_fma(v0, e, v0);
+        x[1] = x[1] * rs; x[3] = x[3] * rs;
     }
-    return fallback;
+    a[A_SO] = slaved ? a[A_SO] * sbr_rcp(__builtin_fma(lam0, span, 1.0)) : a[A_SO];
+    const double u = DOSE ? __builtin_fma(-n0, c14, x[13]) * rs : __builtin_fma(-n0, c14, x[13]);
+    sbr_scatter(a, x);
+    x[7] = xp;
+    x[13] = __builtin_fma(x[10] - x[9], c14, u);
+}
+// m macro intervals of span/m each, closed reactor (the idle phase of the done call: m = ceil(rows / 10))
+SBR_DEV void sbr_b5a_span(const SbrPar& p, double (&x)[SBR_NX], double span, int m, double kla) {
+    const double hm = span * sbr_rcp((double)(m > 0 ? m : 1));
+#pragma unroll 1
+    for (int j = 0; j < m; ++j) sbr_b5a<false>(p, x, hm, kla, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -607,7 +612,8 @@ SBR_DEV int sbr_status_bits(const SbrPar& p, const double (&x)[SBR_NX]) {
 // xs6 receives the interval's start values of the xdot components.
 // TR: where the NO3-PID's e / ie / dcv of every interval go (trajectory export; SbrNoTrace for kernels without one).
 struct SbrNoTrace { SBR_DEV void pid(int, double, double, double) const {} };
-template <typename X6, typename TR>
+// SCH: cfg.scheme at compile time (a kernel instantiation per scheme: the scheme-1 kernels carry no RK4 loop for the intervals).
+template <int SCH, typename X6, typename TR>
 SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& xs6, bool aerobic, const TR& tr) {
     const double t0 = c.t, t1 = t0 + p.t_delta;
     const double span = t1 - t0;
@@ -656,17 +662,15 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    const double h = span * p.inv_substeps;
-    bool rk4 = true;                                   // per lane: the RK4 substeps integrate this interval
-    if (p.scheme == 1) {                               // wave-uniform
+    if constexpr (SCH == 1) {
 #ifdef SBR_B5_ONE_FORM
-        rk4 = sbr_b5a<true>(p, x, span, kla, ec);
+        sbr_b5a<true>(p, x, span, kla, ec);
 #else
-        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) rk4 = sbr_b5a<false>(p, x, span, kla, 0.0);
-        else rk4 = sbr_b5a<true>(p, x, span, kla, ec);
+        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_b5a<false>(p, x, span, kla, 0.0);
+        else sbr_b5a<true>(p, x, span, kla, ec);
 #endif
-    }
-    if (rk4) {                                         // scheme 0: every lane; scheme 1: the lanes behind the stability guard
+    } else {
+        const double h = span * p.inv_substeps;
         if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<0>(p, x, h, p.substeps, kla, 0.0, nold);
         else sbr_rk4<1>(p, x, h, p.substeps, kla, ec, nold);
     }
@@ -697,7 +701,7 @@ SBR_DEV int sbr_phase(const SbrPar& p, double t) {
     // every comparison is false for a NaN: -1
     return (t >= p.T3_0 ? 1 : 0) + (t > p.T3_end ? 1 : 0) + (t > p.T4_end ? 1 : 0) - (t == t ? 0 : 1);
 }
-template <bool LOOP, typename X6, typename TR>
+template <bool LOOP, int SCH, typename X6, typename TR>
 SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6, const TR& tr) {
     a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
     a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
@@ -711,7 +715,7 @@ SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], 
             if (ph > last) {
                 const bool aerobic = (ph & 1) != 0;
                 c.u_do = aerobic ? a0 : 0.0; c.u_ec = aerobic ? 0.0 : a1;
-                sbr_interval(p, c, x, xs6, aerobic, tr);
+                sbr_interval<SCH>(p, c, x, xs6, aerobic, tr);
                 last = ph;
             }
         }
@@ -720,12 +724,12 @@ SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], 
         if (ph >= 0) {
             const bool aerobic = (ph & 1) != 0;
             c.u_do = aerobic ? a0 : 0.0; c.u_ec = aerobic ? 0.0 : a1;
-            sbr_interval(p, c, x, xs6, aerobic, tr);
+            sbr_interval<SCH>(p, c, x, xs6, aerobic, tr);
             const int ph2 = sbr_phase(p, c.t);
             if (__builtin_expect(ph2 > ph, 0)) {
                 const bool aerobic2 = (ph2 & 1) != 0;
                 c.u_do = aerobic2 ? a0 : 0.0; c.u_ec = aerobic2 ? 0.0 : a1;
-                sbr_interval(p, c, x, xs6, aerobic2, tr);
+                sbr_interval<SCH>(p, c, x, xs6, aerobic2, tr);
             }
         }
     }
@@ -936,7 +940,7 @@ SBR_DEV double sbr_draw(const SbrPar& p, double (&x)[SBR_NX], const double (&sx)
     return qw;
 }
 
-template <typename H>
+template <int SCH, typename H>
 SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX]) {
     const double t_set = p.t_settle * p.t_cycle;
     double sx[10], sx_eff;
@@ -952,10 +956,14 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_N
     const double span = p.t_cycle - t_after_draw;
     int n = (int)(span / p.dt);                       // 464 for the reference's schedule
     n = n < 0 ? 0 : (n > 100000 ? 100000 : n);        // every wave terminates whatever t holds
-    double nold[SBR_NX];
+    if constexpr (SCH == 1) {
+        sbr_b5a_span(p, x, span, (n + 9) / 10, kla);  // ceil(rows / 10) macro intervals of the adaptive scheme
+    } else {
+        double nold[SBR_NX];
 #pragma unroll
-    for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    sbr_rk4<0>(p, x, span * sbr_rcp((double)(n > 0 ? n : 1)), n, kla, 0.0, nold);
+        for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
+        sbr_rk4<0>(p, x, span * sbr_rcp((double)(n > 0 ? n : 1)), n, kla, 0.0, nold);
+    }
     hs.push(kla);                                     // Kla.append in Sim_idle (:2578)
     c.kla_last = kla;
     return qw;
@@ -968,7 +976,7 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_N
 // TERMINAL_INLINE = false leaves the terminal phases of the done call to the caller (the fused rollout runs them once, after its
 // loop over the calls: with them inside the loop the compiler keeps their working set alive across it - 3 % of the rollout's
 // time, profiles/r03_notes.md); the reward of a done call does not depend on them unless OCI.
-template <bool OCI, typename H, bool TERMINAL_INLINE = true>
+template <bool OCI, int SCH, typename H, bool TERMINAL_INLINE = true>
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX],
                                double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp) {
     const double kwin = hs.commit_and_window(c);
@@ -988,7 +996,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
         if ((TERMINAL_INLINE || OCI) && p.terminal) {
             sbr_take6(x, xa6);
             const double snh_eff = x[10];            // solubles pass the settler unchanged: eff_component[3] (:2642)
-            qw = sbr_terminal(p, c, hs, x);
+            qw = sbr_terminal<SCH>(p, c, hs, x);
             if (OCI) {
                 ksum = ksum + c.kla_last;            // Sim_idle's Kla.append (:2578)
                 r = sbr_reward_oci(p, 2, c.kla_last, ksum, qw, snh_eff);
@@ -1005,7 +1013,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
 // PID on So with derivative action; interval 0 OVERWRITES Kla[0], which held the incoming bias, so intervals 1.. use the
 // controlled (clamped) Kla of interval 0 as bias (:219,:243); the integral restarts in every phase.  t_start/t_end
 // are wave-uniform.  Returns the last Kla; ksum = sum(Kla), n_iv = number of intervals.
-template <bool FILL>
+template <bool FILL, int SCH>
 SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, double sp, double kla_in,
                                const double (&ld)[SBR_NX], double& ksum) {
     const double t_start = p.cyc_t0[ph], t_end = p.cyc_t1[ph], step = p.cyc_step[ph];   // numpy.linspace: i*step + start, last = stop
@@ -1021,7 +1029,8 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, dou
         if (k > p.Kla_max) { k = p.Kla_max; ie = ie - e * p.cyc_dt; }
         if (k < p.Kla_min) { k = p.Kla_min; ie = ie - e * p.cyc_dt; }
         if (i == 0) bias = k;
-        sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
+        if constexpr (SCH == 1 && !FILL) sbr_b5a<false>(p, x, g1 - g0, k, 0.0);     // scheme 1: every interval but the fill phase's
+        else sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
         sum = sum + k;
         so_prev = so; so = x[8];
     }
@@ -1032,6 +1041,7 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, dou
 // SbrEnv2.step (gym_SBR_env2.py:131-171) = SBR_model_FB.run (SBR_model_FB.py:8-295) + module_reward.py:4-51 for one env:
 // x is the start state in, the end-of-cycle state out; ld the influent with ld[0] = Qin/t_phs1; a[3] the clipped action.
 // obs3 = [Qeff, COD_eff, Snh_eff/30]; diag (SBR_NCYC_DIAG doubles) may be nullptr.
+template <int SCH>
 SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double (&ld)[SBR_NX], double a0, double a1, double a2,
                              double (&obs3)[3], double* diag, int diag_stride) {
     a0 = a0 < 0.0 ? 0.0 : (a0 > 1.0 ? 1.0 : a0); a1 = a1 < 0.0 ? 0.0 : (a1 > 1.0 ? 1.0 : a1);
@@ -1040,11 +1050,11 @@ SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double 
     const double qin = p.WV - x[0];
     double ks1, ks2, ks3, ks4, ks5, ks8;
     // phases 1..5 (fill, anoxic, aerobic, anoxic, aerobic): schedule indices 0..4; the aerated idle is index 5
-    double kl = sbr_cycle_phase<true>(p, x, 0, 0.0, 0.0, ld, ks1);
-    kl = sbr_cycle_phase<false>(p, x, 1, 0.0, kl, ld, ks2);
-    kl = sbr_cycle_phase<false>(p, x, 2, sp3, kl, ld, ks3);
-    kl = sbr_cycle_phase<false>(p, x, 3, 0.0, kl, ld, ks4);
-    kl = sbr_cycle_phase<false>(p, x, 4, sp5, kl, ld, ks5);
+    double kl = sbr_cycle_phase<true, SCH>(p, x, 0, 0.0, 0.0, ld, ks1);
+    kl = sbr_cycle_phase<false, SCH>(p, x, 1, 0.0, kl, ld, ks2);
+    kl = sbr_cycle_phase<false, SCH>(p, x, 2, sp3, kl, ld, ks3);
+    kl = sbr_cycle_phase<false, SCH>(p, x, 3, 0.0, kl, ld, ks4);
+    kl = sbr_cycle_phase<false, SCH>(p, x, 4, sp5, kl, ld, ks5);
     // settle
     double sx[10], sx_eff;
     const double xf = sbr_settle(p, x, p.cyc_tset, sx);
@@ -1062,7 +1072,7 @@ SBR_DEV double sbr_cycle_env(const SbrPar& p, double (&x)[SBR_NX], const double 
     const double eqi = (2 * ss_ + cod + 30 * snkj + 10 * x[9] + 2 * bod5) * (1.0 / 1000) * 0.66;
     const double snh_eff = x[10], sno_eff = x[9];
     // aerated idle from the drawn reactor, bias = last Kla of phase 5 (SBR_model_FB.py:258)
-    sbr_cycle_phase<false>(p, x, 5, sp8, kl, ld, ks8);
+    sbr_cycle_phase<false, SCH>(p, x, 5, sp8, kl, ld, ks8);
     // reward (module_reward.py:4-51): AE_k = 1.32 sum(Kla) td / (n td), the quotient by the wave-uniform n td folded on the host
     const double td = 0.002 / 24;
     const double ae3 = (1.32 * ks3 * td) * p.cyc_inv_ntd[2], ae5 = (1.32 * ks5 * td) * p.cyc_inv_ntd[4];

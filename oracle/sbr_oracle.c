@@ -232,28 +232,34 @@ static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, 
 }
 
 /* ---------------------------------------------------------------------------------- scheme 1 ("B5A", round 5)
- * One control interval by Butcher's six-stage fifth-order scheme with a step count chosen per interval from the plant's own
- * state.  Same operations in the same order as oracle/sbr_ref.py b5a_plan / b5_step / b5a_reaction (bit-identical); the
- * reasoning is written there and in DESIGN.md 4.3. */
+ * A span with Kla and the flows held, by Butcher's six-stage fifth-order scheme with a step count chosen from the plant's own
+ * state at the start of every macro interval (a control interval; the idle phase is cut into ceil(rows/10) of them).  Same
+ * operations in the same order as oracle/sbr_ref.py b5a_plan / b5_step / b5a_span (bit-identical); the reasoning is written
+ * there and in DESIGN.md 4.3.   kind 0: reaction (ec != 0: scaled-mass form)   1: fill (loading)   2: idle */
 #define B5A_SO_SLAVED 1e-9
 #define B5A_Z1 0.3
 #define B5A_Z2 1.0
 #define B5A_Z_STAB 3.0
+#define B5A_N_MAX 64
 
-static void b5a_rhs(const sbro_params* p, const double* y, double v0, double kla, double ec, int hold_so, double* k) {
-    if (ec != 0.0) rhs_reaction_w(p, y, v0, kla, ec, k);
+static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, double kla, double ec, const double* loading,
+                    int hold_so, double* k) {
+    if (kind == 1) sbro_rhs_fill(p, y, kla, loading, k);
+    else if (kind == 2) sbro_rhs_idle(p, y, kla, k);
+    else if (ec != 0.0) rhs_reaction_w(p, y, v0, kla, ec, k);
     else sbro_rhs_reaction(p, y, kla, ec, k);
     if (hold_so) k[8] = 0.0;
 }
 
-/* returns the step count (0 = fell back to RK4 x p->substeps) */
-static int b5a_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
+/* one macro interval; returns the step count */
+static int b5a_macro(const sbro_params* p, int kind, double* x, double span, double kla, double ec, const double* loading) {
     static const double A21 = 0.25, A31 = 0.125, A32 = 0.125, A42 = -0.5, A43 = 1.0, A51 = 3.0 / 16.0, A54 = 9.0 / 16.0,
                         A61 = -3.0 / 7.0, A62 = 2.0 / 7.0, A63 = 12.0 / 7.0, A64 = -12.0 / 7.0, A65 = 8.0 / 7.0,
                         B1 = 7.0 / 90.0, B3 = 32.0 / 90.0, B4 = 12.0 / 90.0, B5 = 32.0 / 90.0, B6 = 7.0 / 90.0;
     const double v0 = x[0];
+    const int dose = (kind == 0 && ec != 0.0);
     double k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX];
-    b5a_rhs(p, x, v0, kla, ec, 0, k1);
+    b5a_rhs(p, kind, x, v0, kla, ec, loading, 0, k1);
     /* the plan */
     const double ss = x[2], xbh = x[5], xba = x[6], so = x[8], snh = x[10];
     const double a1 = ((1 - p->Yh) / p->Yh) * p->muH * (ss / (p->Ks + ss)) * xbh;
@@ -266,30 +272,33 @@ static int b5a_interval(const sbro_params* p, double* x, double span, double kla
     const double z_ub = LAM(so_lo) * span;
     const double lam0 = LAM(0.0);
 #undef LAM
-    const int n = slaved ? 2 : (z_ub < B5A_Z1 ? 1 : (z_ub < B5A_Z2 ? 2 : 4));
-    if (!slaved && n == 4 && lam0 * span / 4 > B5A_Z_STAB) {
-        rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
-        return 0;
+    int n;
+    if (slaved) n = 2;
+    else if (z_ub < B5A_Z1) n = 1;
+    else if (z_ub < B5A_Z2) n = 2;
+    else {                                  /* the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39) */
+        const double q = lam0 * span / B5A_Z_STAB;
+        n = q < 4.0 ? 4 : (!(q < (double)B5A_N_MAX) ? B5A_N_MAX : (int)q + 1);
     }
     const double h = span / n;
     if (slaved) k1[8] = 0.0;
     for (int s = 0; s < n; ++s) {
-        if (s > 0) b5a_rhs(p, x, v0, kla, ec, slaved, k1);
+        if (s > 0) b5a_rhs(p, kind, x, v0, kla, ec, loading, slaved, k1);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A21) * k1[i];
-        b5a_rhs(p, y, v0, kla, ec, slaved, k2);
+        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k2);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A31) * k1[i] + (h * A32) * k2[i];
-        b5a_rhs(p, y, v0, kla, ec, slaved, k3);
+        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k3);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A42) * k2[i] + (h * A43) * k3[i];
-        b5a_rhs(p, y, v0, kla, ec, slaved, k4);
+        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k4);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A51) * k1[i] + (h * A54) * k4[i];
-        b5a_rhs(p, y, v0, kla, ec, slaved, k5);
+        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k5);
         for (int i = 0; i < NX; ++i)
             y[i] = x[i] + (h * A61) * k1[i] + (h * A62) * k2[i] + (h * A63) * k3[i] + (h * A64) * k4[i] + (h * A65) * k5[i];
-        b5a_rhs(p, y, v0, kla, ec, slaved, k6);
+        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k6);
         for (int i = 0; i < NX; ++i)
             x[i] = x[i] + (h * B1) * k1[i] + (h * B3) * k3[i] + (h * B4) * k4[i] + (h * B5) * k5[i] + (h * B6) * k6[i];
     }
-    if (ec != 0.0) {
+    if (dose) {
         const double s_end = x[0] / v0;
         for (int i = 1; i < NX; ++i) x[i] = x[i] / s_end;
     }
@@ -297,11 +306,26 @@ static int b5a_interval(const sbro_params* p, double* x, double span, double kla
     return n;
 }
 
+/* m macro intervals of span/m each; returns the step count of the last one */
+static int b5a_span(const sbro_params* p, int kind, double* x, double span, int m, double kla, double ec, const double* loading) {
+    const double hm = span / m;
+    int n = 0;
+    for (int j = 0; j < m; ++j) n = b5a_macro(p, kind, x, hm, kla, ec, loading);
+    return n;
+}
+
 /* scheme-aware integration of one reaction interval (python: SbrOsRef._integrate); returns the step count (-1: scheme 0) */
 int sbro_reaction_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
-    if (p->scheme == 1) return b5a_interval(p, x, span, kla, ec);
+    if (p->scheme == 1) return b5a_span(p, 0, x, span, 1, kla, ec, 0);
     rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
     return -1;
+}
+
+/* the idle phase (kind 2) under the handle's scheme: scheme 1 cuts its `rows` RK4-substep-long span into ceil(rows/10) macro
+ * intervals of the adaptive scheme */
+static void idle_span(const sbro_params* p, double* x, double span, int rows, double kla) {
+    if (p->scheme == 1) b5a_span(p, 2, x, span, (rows + 9) / 10, kla, 0, 0);
+    else rk4_span(p, 2, x, span, rows, kla, 0, 0);
 }
 
 void sbro_rk4(const sbro_params* p, int kind, double* x, double span, int n, double kla, double ec,
@@ -615,7 +639,7 @@ static void terminal(const sbro_params* p, sbro_env* e) {
     if (kla > p->Kla_max) { kla = p->Kla_max; e->ie_do = e->ie_do - err * p->dt; }
     if (kla < p->Kla_min) { kla = p->Kla_min; e->ie_do = e->ie_do - err * p->dt; }
     const int n_rows = (int)((p->t_cycle - t_after_draw) / p->dt);
-    rk4_span(p, 2, x, p->t_cycle - t_after_draw, n_rows, kla, 0, 0);
+    idle_span(p, x, p->t_cycle - t_after_draw, n_rows, kla);
     for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];   /* Kla.append, :2578 */
     e->kla_hist[KLA_HIST - 1] = kla;
     e->kla_sum = e->kla_sum + kla;
@@ -732,7 +756,8 @@ static double cycle_phase(const sbro_params* p, double* x, double t_start, doubl
         if (k > p->Kla_max) { k = p->Kla_max; ie = ie - e * p->cyc_dt; }
         if (k < p->Kla_min) { k = p->Kla_min; ie = ie - e * p->cyc_dt; }
         if (i == 0) bias = k;
-        rk4_span(p, loading ? 1 : 2, x, g1 - g0, p->substeps, k, 0, loading);
+        if (p->scheme == 1 && !loading) b5a_span(p, 2, x, g1 - g0, 1, k, 0, 0);     /* scheme 1: every interval but the fill phase's */
+        else rk4_span(p, loading ? 1 : 2, x, g1 - g0, p->substeps, k, 0, loading);
         sum = sum + k;
         if (kla_log) kla_log[i] = k;
         so_prev = so; so = x[8];

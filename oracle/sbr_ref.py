@@ -184,18 +184,20 @@ def rk4_reaction_w(x, t0, t1, n, kla, ec):
 #     gate by the NO3-PID -> dosing loop in the golden episode random_b; two steps: 0.0008);
 #   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span, So_lo = the lowest So a linear projection over the interval
 #     reaches (consumption slows as So falls, so the projection bounds So from below and z from above);
-#   * a four-step interval whose worst-case lam(0) h exceeds Z_STAB (Butcher-5 is stable on the real axis up to 3.39) falls
-#     back to the RK4 substeps, stable to lam dt = 2.78.
+#   * in the last case - the knee, where So moves through K_OH - n = max(4, floor(lam(0) span / 3.0) + 1): the worst-case
+#     lam(0) h stays below 3.0 (Butcher-5 is stable on the real axis up to 3.39; the reference plant never needs more than 4);
+#   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) is cut into ceil(rows/10) macro intervals, each
+#     planned like a control interval.
 # oracle/sbr_oracle.c b5a_interval does the same operations in the same order (bit-identical, tests/test_oracle_golden.py).
-B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB = 1e-9, 0.3, 1.0, 3.0
+B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB, B5A_N_MAX = 1e-9, 0.3, 1.0, 3.0, 64
 _A21, _A31, _A32, _A42, _A43, _A51, _A54 = 0.25, 0.125, 0.125, -0.5, 1.0, 3.0 / 16.0, 9.0 / 16.0
 _A61, _A62, _A63, _A64, _A65 = -3.0 / 7.0, 2.0 / 7.0, 12.0 / 7.0, -12.0 / 7.0, 8.0 / 7.0
 _B1, _B3, _B4, _B5, _B6 = 7.0 / 90.0, 32.0 / 90.0, 12.0 / 90.0, 32.0 / 90.0, 7.0 / 90.0
 
 
 def b5a_plan(x, k1_so, span, kla):
-    """(n, slaved, fallback, lam0): the step count of one interval from its start state, the slope of So there (first stage
-    of the first step, which does not depend on the step size), the span and Kla."""
+    """(n, slaved, lam0): the step count of one macro interval from its start state, the slope of So there (first stage of
+    the first step, which does not depend on the step size), the span and Kla."""
     ss, xbh, xba, so, snh = x[2], x[5], x[6], x[8], x[10]
     a1 = ((1 - P.YH) / P.YH) * P.MUH * (ss / (P.KS + ss)) * xbh
     a3 = ((4.57 - P.YA) / P.YA) * P.MUA * (snh / (P.KNH + snh)) * xba
@@ -204,12 +206,20 @@ def b5a_plan(x, k1_so, span, kla):
         return a1 * P.KOH / ((P.KOH + s) * (P.KOH + s)) + a3 * P.KOA / ((P.KOA + s) * (P.KOA + s)) + kla
     slaved = (abs(so) < B5A_SO_SLAVED) and (kla * P.SO_SAT * span < B5A_SO_SLAVED)
     proj = so + k1_so * span
-    so_lo = max(0.0, min(so, proj))
+    lo1 = proj if proj < so else so
+    so_lo = lo1 if lo1 > 0.0 else 0.0
     z_ub = lam(so_lo) * span
     lam0 = lam(0.0)
-    n = 2 if slaved else (1 if z_ub < B5A_Z1 else (2 if z_ub < B5A_Z2 else 4))
-    fallback = (not slaved) and n == 4 and (lam0 * span / 4 > B5A_Z_STAB)
-    return n, slaved, fallback, lam0
+    if slaved:
+        n = 2
+    elif z_ub < B5A_Z1:
+        n = 1
+    elif z_ub < B5A_Z2:
+        n = 2
+    else:                                   # the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39)
+        q = lam0 * span / B5A_Z_STAB
+        n = 4 if q < 4.0 else (B5A_N_MAX if not (q < float(B5A_N_MAX)) else int(q) + 1)
+    return n, slaved, lam0
 
 
 def b5_step(f, x, h, k1, hold_so):
@@ -228,22 +238,22 @@ def b5_step(f, x, h, k1, hold_so):
     return x + (h * _B1) * k1 + (h * _B3) * k3 + (h * _B4) * k4 + (h * _B5) * k5 + (h * _B6) * k6
 
 
-def b5a_reaction(x, t0, t1, n_sub, kla, ec):
-    """One control interval of scheme 1.  n_sub: the RK4 substep count of the fall-back.  Returns (x_end, n) with n = 0 for
-    an interval that fell back."""
+def b5a_macro(kind, x, span, kla, ec=0.0, loading=None):
+    """One macro interval of scheme 1.  kind 0: reaction (ec != 0: scaled-mass form), 1: fill (loading), 2: idle.
+    Returns (x_end, n)."""
     x = np.array(x, dtype=np.float64)
-    span = t1 - t0
     v0 = x[0]
-    if ec != 0:
-        f = lambda y: rhs_reaction_w(y, v0, kla, ec)       # noqa: E731   scaled-mass variables, as rk4_reaction_w
+    dose = kind == 0 and ec != 0
+    if kind == 1:
+        f = lambda y: rhs_fill(y, 0.0, kla, loading)        # noqa: E731
+    elif kind == 2:
+        f = lambda y: rhs_idle(y, 0.0, kla)                 # noqa: E731
+    elif dose:
+        f = lambda y: rhs_reaction_w(y, v0, kla, ec)        # noqa: E731   scaled-mass variables, as rk4_reaction_w
     else:
         f = lambda y: rhs_reaction(y, 0.0, kla, ec)         # noqa: E731
     k1 = f(x)
-    n, slaved, fallback, lam0 = b5a_plan(x, k1[8], span, kla)
-    if fallback:
-        if ec != 0:
-            return rk4_reaction_w(x, t0, t1, n_sub, kla, ec), 0
-        return rk4(rhs_reaction, x, t0, t1, n_sub, (kla, ec)), 0
+    n, slaved, lam0 = b5a_plan(x, k1[8], span, kla)
     h = span / n
     if slaved:
         k1[8] = 0.0
@@ -253,11 +263,21 @@ def b5a_reaction(x, t0, t1, n_sub, kla, ec):
             if slaved:
                 k1[8] = 0.0
         x = b5_step(f, x, h, k1, slaved)
-    if ec != 0:
+    if dose:
         s_end = x[0] / v0
         x[1:] = x[1:] / s_end
     if slaved:
         x[8] = x[8] / (1.0 + lam0 * span)
+    return x, n
+
+
+def b5a_span(kind, x, span, m, kla, ec=0.0, loading=None):
+    """m macro intervals of span/m each (a control interval: m = 1; the idle phase: ceil(rows/10)).  Returns (x_end, n of
+    the last macro interval)."""
+    hm = span / m
+    n = 0
+    for _ in range(m):
+        x, n = b5a_macro(kind, x, hm, kla, ec, loading)
     return x, n
 
 
@@ -307,9 +327,11 @@ class SbrOsRef:
             rows = odeint(f, x, grid, args=args)
             return rows[-1].copy(), rows
         if f is rhs_reaction and self.scheme == 1:
-            x1, n = b5a_reaction(x, t0, t1, n_sub, *args)
+            x1, n = b5a_span(0, x, t1 - t0, 1, *args)
             self.step_counts.append(n)
             return x1, None
+        if f is rhs_idle and self.scheme == 1:
+            return b5a_span(2, x, t1 - t0, (n_sub + 9) // 10, args[0])[0], None
         if f is rhs_reaction and args[1] != 0:          # a dosing interval: RK4 on the scaled-mass system (rk4_reaction_w)
             return rk4_reaction_w(x, t0, t1, n_sub, *args), None
         return rk4(f, x, t0, t1, n_sub, args), None

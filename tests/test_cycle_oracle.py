@@ -2,6 +2,7 @@
 SbrEnv2, captured by oracle/gen_golden.py: per phase the incoming state and bias, every interval's Kla, the end state;
 settler, draw, effluent quality, observation and reward)."""
 import numpy as np
+import pytest
 from conftest import gate, golden
 
 from oracle import sbr_oracle as O
@@ -40,7 +41,7 @@ def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables):
     for c in range(len(g["actions"])):
         st0 = py.reset(g["rnd"][c])
         pst, pr, _, _ = py.step(g["actions"][c])
-        b = O.OracleCycleBatch(1)
+        b = O.OracleCycleBatch(1, O.default_params(scheme=0))
         cst0 = b.reset(influent_mix(means[0], stds[0], g["rnd"][c])[None])
         st, r, diag, log = b.step_logged(0, g["actions"][c])
         assert np.array_equal(cst0[0], st0) and np.array_equal(st, pst) and r == pr
@@ -51,13 +52,15 @@ def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables):
         assert np.array_equal(diag[3:8], py.eff[1:])
 
 
-def test_rk4_cycle_inside_gate_of_reference(tables):
-    """RK4 with 10 substeps per control interval against the reference's LSODA, closed loop over the whole cycle.
-    Measured: phase-end states <= 0.018 of the gate, rewards within 3.2e-8, Qw within 1.7e-7 relative."""
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_rk4_cycle_inside_gate_of_reference(tables, scheme):
+    """RK4 with 10 substeps per control interval (scheme 0) and the adaptive Butcher-5 of round 5 (scheme 1: every interval but
+    the fill phase's) against the reference's LSODA, closed loop over the whole cycle.
+    Measured: phase-end states <= 0.018 of the gate, rewards within 3.2e-8, Qw within 1.7e-7 relative (scheme 0)."""
     means, stds = tables
     g = golden("sbrv2_cycles")
     n = len(g["actions"])
-    b = O.OracleCycleBatch(n, nthreads=2)
+    b = O.OracleCycleBatch(n, O.default_params(scheme=scheme), nthreads=2)
     b.reset(np.stack([influent_mix(means[0], stds[0], g["rnd"][c]) for c in range(n)]))
     st, r, diag = b.step(g["actions"])
     last = g["ph_x_end"][g["phase_first"] + 5]

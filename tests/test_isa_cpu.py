@@ -12,10 +12,13 @@ from conftest import ROOT
 
 from gym_sbr2_amd import build as B
 
-K_STEP = "_Z6k_stepIffLi256ELb0EE"        # k_step<float, float, 256, false>: the kernel bench.py times
-K_STEP_SMALL = "_Z6k_stepIffLi64ELb0EE"     # the 64-thread-workgroup build used up to 49152 envs
-K_ROLLOUT = "_Z9k_rolloutILb0EE"
-K_CYCLE = "_Z7k_cycleIffE"
+K_STEP = "_Z6k_stepIffLi256ELb0ELi1EE"       # k_step<float, float, 256, false, 1>: the kernel bench.py times (scheme 1)
+K_STEP_SMALL = "_Z6k_stepIffLi64ELb0ELi1EE"    # the 64-thread-workgroup build used up to 49152 envs
+K_STEP_RK4 = "_Z6k_stepIffLi256ELb0ELi0EE"   # cfg.scheme = 0: ten RK4 substeps per interval
+K_ROLLOUT = "_Z9k_rolloutILb0ELi1EE"
+K_ROLLOUT_RK4 = "_Z9k_rolloutILb0ELi0EE"
+K_CYCLE = "_Z7k_cycleIffLi1EE"
+K_CYCLE_RK4 = "_Z7k_cycleIffLi0EE"
 K_RESET = "_Z7k_resetIfLb0EE"
 K_RESET_CARRY = "_Z7k_resetIfLb1EE"
 K_CYCLE_RESET = "_Z13k_cycle_resetIfLb0EE"
