@@ -63,6 +63,10 @@ CALLS_PER_EPISODE = 463
 # observations): a LOWER bound of the work per env-step.  tests/test_isa_cpu.py asserts both figures against the compiler's output.
 FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 468, "filling": 590}      # filling: k_cycle's / k_reset's loop, (426 x 2 + 229 + 88 + 12) / 2
 SUBSTEPS = 10
+# cfg.scheme = 1 (round 5, the default): float64 operations of ONE step of the adaptive Butcher-5 integrator (six right-hand
+# sides), counted in the ISA of sbr_b5a's step loops (296 FMA x 2 + 169 MUL + 6 ADD + 6 RCP; with dosing 334 x 2 + 179 + 18 + 6);
+# tests/test_isa_cpu.py asserts both.  How many steps an interval takes is decided per env (1, 2 or 4).
+FP64_FLOP_PER_B5_STEP = {"plain": 773, "dosing": 871}
 # vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
 # vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -85,20 +89,32 @@ def reference_cpu():
             "script": "oracle/time_reference.py"}
 
 
-def cpu_baseline(n_envs=16384, calls=463, physical=True):
-    """The CPU oracle (a C port of the same algorithm: RK4, fp64, OpenMP over envs) timed on this box's host cores, on a
-    bounded sample of the same workload.  Reported beside the GPU number; it is not the target."""
+def cpu_baseline(n_envs=16384, calls=463, physical=True, scheme=1):
+    """The CPU oracle (a C port of the same algorithm: the same integrator scheme, fp64, OpenMP over envs) timed on this box's
+    host cores, on a bounded sample of the same workload.  Reported beside the GPU number; it is not the target.
+    Its first pass also counts, per call of the episode, what the integrator did on this workload (the GPU does not report it):
+    the share of 64-env groups (= wavefronts) with at least one lane dosing carbon, and under scheme 1 the mean step count per
+    env and per wavefront (a wavefront runs its slowest lane's count)."""
     import numpy as np
     from oracle import sbr_oracle as O
     from gym_sbr2_amd.vec_env import load_influent_tables
     means, stds = load_influent_tables()
     cores = min(len(os.sched_getaffinity(0)), 16)
     scen = ((4 + np.arange(n_envs) % 4) if physical else (np.arange(n_envs) % 8)).astype(np.int32)
-    b = O.OracleBatch(n_envs, nthreads=cores)
+    b = O.OracleBatch(n_envs, O.default_params(scheme=scheme), nthreads=cores)
     infl = b.mix(means, stds, scen, b.normals(0))
     rs = np.random.RandomState(0)
     acts = [np.column_stack([rs.uniform(0, 2.5 if physical else 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
     best = 0.0
+    per_call = {"dosing_wave_share": [], "steps_lane_mean": [], "steps_wave_mean": []}
+    b.reset(infl)
+    for a in acts:                     # untimed: the integrator's statistics per call (+ warms the caches)
+        b.step(a, want_obs=False)
+        ec = b.envs["ec_last"][:n_envs - n_envs % 64].reshape(-1, 64)
+        per_call["dosing_wave_share"].append(float((ec != 0).any(axis=1).mean()))
+        if scheme == 1:                # a phase-boundary call records its second interval's count; three calls per episode
+            st = b.envs["scheme_steps"][:n_envs - n_envs % 64].reshape(-1, 64)
+            per_call["steps_lane_mean"].append(float(st.mean())); per_call["steps_wave_mean"].append(float(st.max(axis=1).mean()))
     for _ in range(3):                 # best of three: shared hosts are noisy (about 0.5 s each: 7.6 M env-steps)
         b.reset(infl)
         b.step(acts[0], want_obs=False)
@@ -108,7 +124,7 @@ def cpu_baseline(n_envs=16384, calls=463, physical=True):
         best = max(best, n_envs * calls / (time.perf_counter() - t0))
     # "1 core and all cores" - the same port on ONE thread, a sample sized for about a second
     n1 = 2048
-    b1 = O.OracleBatch(n1, nthreads=1)
+    b1 = O.OracleBatch(n1, O.default_params(scheme=scheme), nthreads=1)
     infl1 = infl[:n1].copy()
     best1 = 0.0
     for _ in range(2):
@@ -117,9 +133,9 @@ def cpu_baseline(n_envs=16384, calls=463, physical=True):
         for a in acts:
             b1.step(a[:n1], want_obs=True)
         best1 = max(best1, n1 * calls / (time.perf_counter() - t0))
-    return {"value": best, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d step() calls of the same workload, oracle/sbr_oracle.c with %d OpenMP threads, best of 3"
-                      % (n_envs, calls, cores),
+    return {"value": best, "unit": "env-steps/s", "cores": cores, "kind": "port", "scheme": scheme, "per_call": per_call,
+            "sample": "%d envs x %d step() calls of the same workload, oracle/sbr_oracle.c (cfg.scheme = %d) with %d OpenMP threads, "
+                      "best of 3" % (n_envs, calls, scheme, cores),
             "single_thread": {"value": best1, "unit": "env-steps/s", "cores": 1,
                               "sample": "%d envs x %d step() calls of the same workload on one thread, best of 2" % (n1, calls)},
             "reference": reference_cpu()}
@@ -148,6 +164,51 @@ def pmc_record(lib_hash, profiles_dir=None):
                   "and scripts/pmc_summarise.py" % (lib_hash[:12], "; ".join(seen) or "none"))
 
 
+def hash_matched(pattern, lib_hash, profiles_dir=None, key="library_source_hash"):
+    """Committed profiles/<pattern> records (newest first) whose `key` equals the hash of the library being timed."""
+    import glob
+    out = []
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), pattern)), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if lib_hash and rec.get(key) == lib_hash:
+            rec["_file"] = os.path.relpath(path, ROOT)
+            out.append(rec)
+    return out
+
+
+def larger_batches(lib_hash, profiles_dir=None):
+    """north_star's '>= 40 % of HBM roofline on one MI355X' is a statement about the chip, and the configured
+    65 536 envs are one wavefront per SIMD; what larger launches reach is carried by committed bench lines of THIS library
+    (profiles/r*_bench_config2_n<envs>.json, `python bench.py --envs-per-gpu N`; each line records the hash of the library it
+    timed as config.library_source_hash).  A committed constant under the same rule as `traffic`; absent if no file matches."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "r*_bench_config2_n*.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        cfg = rec.get("config", {})
+        n = cfg.get("envs_per_gpu")
+        if not lib_hash or cfg.get("library_source_hash") != lib_hash or n in (None, 65536) or str(n) in out:
+            continue
+        r = rec["roofline"]
+        out[str(n)] = {"frac": r["frac"], "env_steps_per_s": rec["value"], "us_per_launch": rec["ms_per_step"] * 1e3,
+                       "file": os.path.relpath(path, ROOT)}
+    return out or None
+
+
+def serial_bound_record(lib_hash, profiles_dir=None):
+    """The two measured constants of roofline.serial_bound (arithmetic of one call at the single-wave issue rate, period of an
+    empty dependent launch) live in a committed profiles/r*_serial_bound.json keyed by the library they were measured on
+    (they used to be literals in this file and went stale silently)."""
+    recs = hash_matched("r*_serial_bound.json", lib_hash, profiles_dir)
+    return recs[0] if recs else None
+
+
 def loaded_library_hash():
     from gym_sbr2_amd import _capi
     try:
@@ -163,10 +224,14 @@ FILL_INTERVALS = 24            # the first phase integrates the filling right-ha
 
 def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
     """SBR-v2: every step is reset (influent draw) + one whole cycle, for all envs of this rank."""
-    from gym_sbr2_amd import SbrEnv2Vec
+    from gym_sbr2_amd import SbrEnv2Vec, _capi
     n_local = args.envs_per_gpu or 65536
     n_global = n_local * world
-    env = SbrEnv2Vec(n_local, device=local_rank, first_env_id=rank * n_local)
+    cfg = _capi.default_config()
+    if args.scheme is not None:
+        cfg.scheme = args.scheme
+    scheme = int(cfg.scheme)
+    env = SbrEnv2Vec(n_local, device=local_rank, first_env_id=rank * n_local, config=cfg)
     scenario = ((torch.arange(n_local, device=dev) + rank * n_local) % 8).to(torch.int32)
     gen = torch.Generator(device=dev); gen.manual_seed(4321 + rank)
     pool = torch.rand(16, n_local, 3, device=dev, generator=gen)
@@ -208,6 +273,10 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
     fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
             "flop_per_env_step": flop_per_cycle / INTERVALS_PER_CYCLE,
             "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work"}
+    if scheme == 1:       # the step count of every non-fill interval is decided per env; this path has no CPU sample to count them
+        fp64 = {"achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "note": "cfg.scheme = 1: 504 of the 528 intervals take 1, 2 or 4 Butcher-5 steps (773 FLOP each) as each env's state "
+                        "demands, the 24 fill intervals ten RK4 substeps; read issue_slot_frac (committed PMC profile) for utilisation"}
     rec, why = pmc_record(loaded_library_hash())
     traffic = None
     if rec and "cycle" in rec and n_local == rec.get("envs_per_launch", 65536):
@@ -222,10 +291,10 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "SBR-v2 per-cycle env (SURVEY.md 8f-3): %d envs/GPU, one step = reset + one whole 12 h cycle = %d "
-                                  "control intervals of RK4 (10 substeps); value counts control intervals" % (n_local, INTERVALS_PER_CYCLE),
-                      "envs_per_gpu": n_local, "envs_total": n_global, "cycles_per_s": n_global * steps / elapsed,
+                                  "control intervals (cfg.scheme = %d); value counts control intervals" % (n_local, INTERVALS_PER_CYCLE, scheme),
+                      "scheme": scheme, "envs_per_gpu": n_local, "envs_total": n_global, "cycles_per_s": n_global * steps / elapsed,
                       "clock_priming_s": PRIME_SECONDS,
-                      "kernel": "k_cycle<float,float> (+ k_cycle_reset)"},
+                      "kernel": "k_cycle<float,float,%d> (+ k_cycle_reset)" % scheme},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                         "traffic": traffic, "traffic_unit": why, "avg_launch_us": per_launch_s * 1e6,
                         "fp64_valu": fp64, "headline": "fp64_valu",
@@ -247,6 +316,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--policy", default="physical", choices=["physical", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scheme", type=int, default=None, choices=[0, 1],
+                    help="cfg.scheme: 1 (library default) adaptive Butcher-5 per interval, 0 ten RK4 substeps (rounds 1-4)")
     args = ap.parse_args()
 
     # Native libraries print to fd 1 (RCCL writes a five-line version banner when a communicator is created); the contract is
@@ -299,6 +370,9 @@ def main():
     physical = args.policy == "physical"
     do_max = 2.5 if physical else 8.0
     cfg = _capi.default_config()
+    if args.scheme is not None:
+        cfg.scheme = args.scheme
+    scheme = int(cfg.scheme)
     cfg.act_DO_max = do_max               # what the fused rollout's on-device policy draws from (and clips to)
     # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK
     sh = ShardedSbrOS(n_global, rank=rank, world=world, device=dev_index, out_dtype=torch.float32, config=cfg)
@@ -323,7 +397,7 @@ def main():
     gbufs = sh.gather_buffers(torch.float32)          # float64 row, float32 send, float32 [n_global] recv: allocated once, here
     status_snap = torch.empty(n_local, dtype=torch.float64, device=dev)
     dist_up = world > 1 or force_dist
-    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0, "allgathers": 0}
+    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0, "allgathers": 0, "call_ranges": []}
 
     def end_of_episode():
         # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync, no allocation):
@@ -357,6 +431,7 @@ def main():
                 e1.record()
                 seg_events.append((e0, e1, m))
                 c0 = state["in_episode"]
+                acct["call_ranges"].append((c0, c0 + m))
                 acct["anoxic_calls"] += sum(max(0, min(c0 + m, hi) - max(c0, lo)) for lo, hi in ANOXIC_CALLS)
             state["in_episode"] += m
             done += m
@@ -403,7 +478,7 @@ def main():
     run(min(args.warmup, 1), record=True)
     torch.cuda.synchronize(dev)
     seg_events.clear()
-    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0, allgathers=0)
+    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0, allgathers=0, call_ranges=[])
     episodes_before = state["episode"]
     t0 = time.perf_counter()
     gap_ms = (t0 - t_primed) * 1e3              # (diagnostic) host time between the end of clock priming and the timed region
@@ -461,22 +536,46 @@ def main():
                         "moved)" % (rr["calls_per_launch"], rec["_file"], rr["hbm_bytes_per_env_step"]))
     elif rec:
         traffic_note = "the committed PMC profile covers config2 and config5 only"
-    # float64 work of the timed calls: the RK4 substep loops only, ALL counted at the closed-reactor loop's 430 FLOP per substep
-    # - a lower bound.  A wave with at least one lane dosing carbon runs the dosing loop instead (468 FLOP per substep), but how
-    # many do is a property of the policy, not of the phase: under the bench's random NO3 set-points the PID's output sits at
-    # its lower clamp for most lanes, and 40 % of the wave-calls of an episode take the dosing loop (77 % in the second anoxic
-    # phase, 15 % in the first, 14 % in calls 5..24 - the driver's region; counted with the oracle, profiles/r04_notes.md).
-    # Rounds 2-3 priced every anoxic call at the dosing loop's count; `anoxic_share_of_timed_calls` keeps that phase figure.
+    # The CPU baseline (rank 0 of a 1-GPU run) is taken here, after the timed region, because its first pass also counts what the
+    # integrator did on this workload call by call (the GPU does not report it): which wavefronts dosed, how many steps scheme 1
+    # took.  Those statistics are of the oracle's sample of the same workload (other random draws), not of the timed envs.
+    cpu = cpu_baseline(physical=physical, scheme=scheme) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    timed_calls = [c for lo, hi in acct["call_ranges"] for c in range(lo, hi)]
+
+    def over_timed_calls(key):
+        v = cpu["per_call"].get(key) if cpu else None
+        return (sum(v[c] for c in timed_calls) / len(timed_calls)) if (v and timed_calls) else None
     frac_anoxic = acct["anoxic_calls"] / max(args.steps, 1)
-    flop_per_step = SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]
-    tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12
+    dosing_share = over_timed_calls("dosing_wave_share")
     waves = (n_local + 63) // 64
-    fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-            "flop_per_env_step": flop_per_step, "anoxic_share_of_timed_calls": frac_anoxic,
-            "note": "RK4 substep loops only, every call counted at the closed-reactor loop's ISA count (FMA = 2): a lower bound of "
-                    "the work (waves with a dosing lane run 468 instead of 430 FLOP per substep); one wave per SIMD issues a "
-                    "v_fma_f64 every 5.2 cycles and v_mul/v_add_f64 every 4.3 (scripts/probes/fp64_issue.hip), so ~0.8 of the "
-                    "nominal peak is what a single resident wave can reach"}
+    if scheme == 1:
+        # scheme 1: the work per interval is decided per env (1, 2 or 4 Butcher-5 steps of 773 FLOP; with dosing 871); a
+        # wavefront executes its slowest lane's count with the other lanes masked.  `achieved` counts the USEFUL work (the mean
+        # count per env at the closed-reactor figure: a lower bound), `executed_flop_per_env_step` what the wavefronts issued.
+        steps_lane, steps_wave = over_timed_calls("steps_lane_mean"), over_timed_calls("steps_wave_mean")
+        flop_per_step = steps_lane * FP64_FLOP_PER_B5_STEP["plain"] if steps_lane else None
+        tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12 if flop_per_step else None
+        fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "flop_per_env_step": flop_per_step,
+                "executed_flop_per_env_step": steps_wave * FP64_FLOP_PER_B5_STEP["plain"] if steps_wave else None,
+                "b5_steps_per_interval": {"per_env_mean": steps_lane, "per_wavefront_mean": steps_wave,
+                                          "flop_per_step": FP64_FLOP_PER_B5_STEP, "rk4_equivalent_flop": SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]},
+                "anoxic_share_of_timed_calls": frac_anoxic,
+                "note": "cfg.scheme = 1: Butcher-5 step loops only, counted in the ISA (FMA = 2), step counts from the CPU oracle's "
+                        "sample of the same workload over the same calls of the episode (null with --no-cpu-baseline); scheme 0 "
+                        "spent 4300 FLOP per env-step on the same intervals"}
+    else:
+        # scheme 0: the RK4 substep loops only, ALL counted at the closed-reactor loop's 430 FLOP per substep - a lower bound.  A
+        # wave with at least one lane dosing carbon runs the dosing loop instead (468 FLOP per substep); how many do is a property
+        # of the policy, not of the phase (config.dosing_wave_call_share).
+        flop_per_step = SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]
+        tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12
+        fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                "flop_per_env_step": flop_per_step, "anoxic_share_of_timed_calls": frac_anoxic,
+                "note": "RK4 substep loops only, every call counted at the closed-reactor loop's ISA count (FMA = 2): a lower bound of "
+                        "the work (waves with a dosing lane run 468 instead of 430 FLOP per substep); one wave per SIMD issues a "
+                        "v_fma_f64 every 5.2 cycles and v_mul/v_add_f64 every 4.3 (scripts/probes/fp64_issue.hip), so ~0.8 of the "
+                        "nominal peak is what a single resident wave can reach"}
     if valu_per_wave:
         # share of the VALU issue slots of the launch that carried an instruction: instructions per wave (per launch: one call, or
         # the 463 calls of a fused launch) x 4 cycles (one wave64 fp64 instruction at the nominal rate) x waves per SIMD /
@@ -485,9 +584,10 @@ def main():
         fp64["issue_slot_frac"] = (valu_per_wave * scale * 4.0 * (waves / SIMDS if waves > SIMDS else 1.0)
                                    / (per_launch_s * MAX_CLOCK_GHZ * 1e9))
         fp64["valu_insts_per_wave"] = valu_per_wave * scale
-    workload = {"config1": "configs[1]: 4096 envs/GPU, fixed-step RK4 (10 substeps), deterministic influent, per-step API",
-                "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, fixed-step RK4 (10 substeps), per-step API",
-                "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout"}[args.workload]
+    integ = "adaptive Butcher-5 (cfg.scheme = 1: 1, 2 or 4 steps per interval and env)" if scheme == 1 else "fixed-step RK4 (10 substeps)"
+    workload = {"config1": "configs[1]: 4096 envs/GPU, %s, deterministic influent, per-step API" % integ,
+                "config2": "configs[2]: 65536 envs/GPU, stochastic influent perturbations, %s, per-step API" % integ,
+                "config5": "configs[4]: 65536 envs/GPU, fused on-GPU random-policy rollout, %s" % integ}[args.workload]
     if n_local not in (4096, 65536):
         workload = workload.replace("65536 envs/GPU", "%d envs/GPU" % n_local).replace("4096 envs/GPU", "%d envs/GPU" % n_local)
     if world > 1:
@@ -496,6 +596,57 @@ def main():
         workload += ("; configs[3] shape: sharded over %d GPUs by global env id (gym_sbr2_amd.ShardedSbrOS), one RCCL all-gather of the "
                      "episode returns per episode boundary, at least one inside the timed region (config.allgathers_in_timed_region); "
                      "envs_total %d %s" % (world, n_global, rel))
+    # ---- roofline of the dominant kernel.  Three figures exist for the per-step path; `frac` is the CONSERVATIVE one (VERDICT r4
+    # item 2): the whole-episode average of the committed rocprofv3 --kernel-trace --stats run of THIS library (hash-matched)
+    # when there is one, and never above what this run's own wall clock allows (513 B x N / ms_per_step).
+    #   frac_timed_launches  513 B x N / mean device time of the launches this run timed (HIP events on the launch stream); with the
+    #                        driver's --steps 20 --warmup 5 those are calls 5..24 of an episode: anoxic, two-step intervals, no
+    #                        terminal call, no reset - the most flattering of the three
+    #   frac_wall            513 B x N / (wall time of the K steps / K): includes resets, episode boundaries and host gaps
+    #   frac_episode         513 B x N / AVERAGE duration of every k_step launch of the committed kernel trace of whole episodes
+    algo_bytes = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP
+    frac_timed = achieved / HBM_PEAK_GBPS
+    frac_wall = n_local * ALGO_BYTES_PER_ENV_STEP / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS      # a "step" = one call per env
+    frac_episode = (n_local * ALGO_BYTES_PER_ENV_STEP / (episode["average_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS) if episode else None
+    frac = min(frac_episode, frac_wall) if frac_episode is not None else frac_wall
+    lib_hash = loaded_library_hash()
+    sb = serial_bound_record(lib_hash) if (not fused and n_local == 65536 and traffic) else None
+    serial_bound = None
+    if sb:
+        mem_us = traffic / (HBM_PEAK_GBPS * 1e3)
+        arith = sb["arithmetic_us"]
+        arith_mean = (217 * arith["anoxic"] + 246 * arith["aerobic"]) / 463.0       # 217 anoxic and 246 aerobic calls per episode
+        total = mem_us + arith_mean + sb["dependent_launch_floor_us"]
+        serial_bound = {"memory_us": mem_us, "arithmetic_us": arith, "arithmetic_us_episode_mean": arith_mean,
+                        "dependent_launch_floor_us": sb["dependent_launch_floor_us"], "sum_us": total,
+                        "frac_at_bound": n_local * ALGO_BYTES_PER_ENV_STEP / (total * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        "note": "what three measured numbers add up to when nothing overlaps (one wave per SIMD): memory_us from `traffic` "
+                                "of this library at the roofline's own rate; arithmetic (PIDs + integration, per-wave median of the stamp "
+                                "build) and the period of an empty dependent launch are committed measurements of this library (%s)"
+                                % sb["_file"]}
+    roofline = {"bound": "hbm", "achieved": frac * HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac,
+                "frac_is": ("frac_episode" if (frac_episode is not None and frac_episode <= frac_wall) else "frac_wall"),
+                "frac_timed_launches": frac_timed, "frac_wall": frac_wall, "frac_episode": frac_episode,
+                "traffic": traffic, "traffic_unit": traffic_note,
+                "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
+                "avg_launch_us_episode": episode["average_ns"] * 1e-3 if episode else None,
+                "frac_episode_source": ("%s: %d k_step launches, average %.0f ns (committed constant, measured on this library)"
+                                        % (episode["file"], episode["calls"], episode["average_ns"])) if episode else
+                                       "no committed kernel trace of this library and batch size",
+                "larger_batches": (larger_batches(lib_hash) if (world == 1 and args.envs_per_gpu is None and args.workload == "config2")
+                                   else None),
+                "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
+                                    "host_in_end_of_episode": acct["end_of_episode_ms"],
+                                    "host_in_reset_issue": acct["reset_issue_ms"], "since_clock_priming": gap_ms},
+                "fp64_valu": fp64, "serial_bound": serial_bound,
+                "headline": "fp64_valu" if fused else "hbm",
+                "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
+                         "513-byte per-step CONVENTION, not traffic (`traffic` is what really moves); the kernel is bound by float64 "
+                         "VALU issue - read fp64_valu (issue_slot_frac = share of the VALU issue slots used, frac = FLOP share of the "
+                         "78.6 TFLOP/s vector peak)") if fused else
+                        ("the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
+                         "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu")}
     st_bits = status_snap.to(torch.int64)
     out = {
         "metric": "env-steps/sec (batched)",
@@ -521,45 +672,10 @@ def main():
                    "policy": args.policy,
                    "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
-                   "kernel": "k_rollout<false>" if fused else "k_step<float,float,%d,false>" % (64 if n_local <= 49152 else 256)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_unit": traffic_note,
-                     "algorithmic_bytes_per_launch": n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP,
-                     "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                     "avg_launch_us": per_launch_s * 1e6, "launches_timed": launches,
-                     # `frac` is over the launches this run timed - with --steps 20 that is calls 5..24 of an episode: no
-                     # terminal call (settle / draw / idle, ~290 us once per 463 calls), no reset.  `frac_episode` is the same
-                     # 513 B x N over the AVERAGE duration of every k_step launch of the committed rocprofv3 --kernel-trace
-                     # --stats run of whole episodes, attached only for the library that trace was taken on (source hash)
-                     "frac_episode": (n_local * ALGO_BYTES_PER_ENV_STEP / (episode["average_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS
-                                      if episode else None),
-                     "avg_launch_us_episode": episode["average_ns"] * 1e-3 if episode else None,
-                     "frac_episode_source": ("%s: %d k_step launches, average %.0f ns (committed constant, measured on this library)"
-                                             % (episode["file"], episode["calls"], episode["average_ns"])) if episode else
-                                            "no committed kernel trace of this library and batch size",
-                     "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
-                                         "host_in_end_of_episode": acct["end_of_episode_ms"],
-                                         "host_in_reset_issue": acct["reset_issue_ms"],
-                                         "since_clock_priming": gap_ms},
-                     "fp64_valu": fp64,
-                     # what three measured numbers add up to when nothing overlaps (one wave per SIMD): the launch's memory traffic
-                     # at the roofline's own rate + PIDs and RK4 at the single-wave issue rate (stamp build, both batch sizes) + the
-                     # period of an EMPTY dependent launch of this footprint (graph replay).  DESIGN.md section 5.
-                     "serial_bound": ({"memory_us": traffic / (HBM_PEAK_GBPS * 1e3), "arithmetic_us": 6.3, "dependent_launch_floor_us": 1.82,
-                                       "sum_us": traffic / (HBM_PEAK_GBPS * 1e3) + 6.3 + 1.82,
-                                       "frac_at_bound": n_local * ALGO_BYTES_PER_ENV_STEP / ((traffic / (HBM_PEAK_GBPS * 1e3) + 6.3 + 1.82) * 1e-6)
-                                                        / 1e9 / HBM_PEAK_GBPS,
-                                       "note": "memory_us from `traffic` of this library; the other two are committed measurements "
-                                               "(profiles/r04_step_timeline.log, profiles/r02_notes.md), not taken by this run"}
-                                      if (traffic and not fused and n_local == 65536) else None),
-                     "headline": "fp64_valu" if fused else "hbm",
-                     "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
-                              "513-byte per-step CONVENTION, not traffic (`traffic` is what really moves); the kernel is bound by float64 "
-                              "VALU issue - read fp64_valu (issue_slot_frac = share of the VALU issue slots used, frac = FLOP share of the "
-                              "78.6 TFLOP/s vector peak)") if fused else
-                             ("the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
-                              "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu")},
+                   "scheme": scheme, "library_source_hash": lib_hash,
+                   "dosing_wave_call_share": dosing_share,
+                   "kernel": ("k_rollout<false,%d>" % scheme) if fused else "k_step<float,float,%d,false,%d>" % (64 if n_local <= 49152 else 256, scheme)},
+        "roofline": roofline,
         "env_status": {"near_pole_frac_last_episode": float(((st_bits & _capi.ST_NEAR_POLE) != 0).float().mean().item())
                        if state["episode"] > 2 else None,
                        "negative_frac_last_episode": float(((st_bits & _capi.ST_NEGATIVE) != 0).float().mean().item())
@@ -569,8 +685,10 @@ def main():
                                "keeps every env inside the model's domain; the uniform one drives ammonia negative in most envs (the "
                                "reference model has no guards) - arithmetic cost is the same either way"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(physical=physical)
+    if cpu is not None:
+        cpu = dict(cpu)
+        cpu.pop("per_call", None)             # 3 x 463 floats: summarised above (fp64_valu, config.dosing_wave_call_share)
+        out["cpu_baseline"] = cpu
     env.close()
     if world > 1 or force_dist:
         dist.barrier()

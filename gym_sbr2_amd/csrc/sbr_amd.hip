@@ -771,11 +771,12 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
 }
 
 // ------------------------------------------------------------------------------------------- rollout
-#ifndef SBR_ROLLOUT_WAVES
-#define SBR_ROLLOUT_WAVES 2
-#endif
-template <bool OCI, int SCH>
-__global__ __launch_bounds__(SBR_BLOCK, SBR_ROLLOUT_WAVES) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
+// WAVES: resident waves per SIMD the register budget is cut for.  Scheme 1 keeps more state live (five 9-vectors and the step
+// constants of the Butcher-5 steps): capped at 256 registers for two waves per SIMD it spills ~170 B per lane to scratch, which
+// pays only where two waves ARE resident - launches above 98 304 envs; up to there the uncapped build runs (measured, round 5:
+// 65 536 envs 6.6 against 7.3 us per call, 131 072 envs 11.6 against 10.8).
+template <bool OCI, int SCH, int WAVES>
+__global__ __launch_bounds__(SBR_BLOCK, WAVES) void k_rollout(SbrPar p, SbrBuf b, int32_t n_steps, uint64_t policy_seed,
                                                       double* __restrict__ returns, float* __restrict__ actions_out) {
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
@@ -867,8 +868,8 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
 }
 
 // SbrEnv2.step: one whole 12 h cycle per env (528 control intervals x 10 RK4 substeps) in one launch.
-template <typename OutT, typename ActT, int SCH>
-__global__ __launch_bounds__(SBR_BLOCK, 2) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
+template <typename OutT, typename ActT, int SCH, int WAVES>
+__global__ __launch_bounds__(SBR_BLOCK, WAVES) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {
     const uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * SBR_BLOCK, i = i0 + l;
@@ -1141,6 +1142,9 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     }
 }
 
+#ifndef SBR_ONE_WAVE_MAX_ENVS
+#define SBR_ONE_WAVE_MAX_ENVS 98304     // up to 1.5 waves per SIMD the fused scheme-1 kernels run their uncapped-register build
+#endif
 #ifndef SBR_SMALL_BATCH
 #define SBR_SMALL_BATCH 49152       // up to this many envs k_step runs in 64-thread workgroups (measured: profiles/r02_ab_block.log)
 #endif
@@ -1404,11 +1408,13 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
-#define CSTEP(T, A) do { if (e->cfg.scheme == 1) hipLaunchKernelGGL((k_cycle<T, A, 1>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag); \
-                         else hipLaunchKernelGGL((k_cycle<T, A, 0>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag); } while (0)
+#define CSTEP1(T, A, S, W) hipLaunchKernelGGL((k_cycle<T, A, S, W>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
+#define CSTEP(T, A) do { if (e->cfg.scheme == 1) { if (e->n <= SBR_ONE_WAVE_MAX_ENVS) CSTEP1(T, A, 1, 1); else CSTEP1(T, A, 1, 2); } \
+                         else CSTEP1(T, A, 0, 2); } while (0)
     if (e->cfg.out_f64) { if (e->cfg.act_f64) CSTEP(double, double); else CSTEP(double, float); }
     else { if (e->cfg.act_f64) CSTEP(float, double); else CSTEP(float, float); }
 #undef CSTEP
+#undef CSTEP1
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }
@@ -1416,10 +1422,11 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
 int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* returns, float* actions_out, void* stream) {
     if (!e || n_steps < 0) return fail(e, SBR_ERR_INVALID, "sbr_rollout: bad argument");
     ON_DEVICE(e);
-#define ROLL(O, S) hipLaunchKernelGGL((k_rollout<O, S>), grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, n_steps, \
-                                      policy_seed, returns, actions_out)
-    if (e->cfg.reward_kind == 2) { if (e->cfg.scheme == 1) ROLL(true, 1); else ROLL(true, 0); }
-    else { if (e->cfg.scheme == 1) ROLL(false, 1); else ROLL(false, 0); }
+#define ROLL(O, S, W) hipLaunchKernelGGL((k_rollout<O, S, W>), grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, \
+                                         n_steps, policy_seed, returns, actions_out)
+    const bool one_wave = e->cfg.scheme == 1 && e->n <= SBR_ONE_WAVE_MAX_ENVS;
+    if (e->cfg.reward_kind == 2) { if (e->cfg.scheme == 1) { if (one_wave) ROLL(true, 1, 1); else ROLL(true, 1, 2); } else ROLL(true, 0, 2); }
+    else { if (e->cfg.scheme == 1) { if (one_wave) ROLL(false, 1, 1); else ROLL(false, 1, 2); } else ROLL(false, 0, 2); }
 #undef ROLL
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;

@@ -23,6 +23,20 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pmc_write -o
 echo "WRITE_SIZE pass done"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace -d $out/pmc_sq -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_sq.json 2> $out/pmc_sq.err || echo "SQ pass failed (optional)"
 python3 scripts/pmc_summarise.py $tag
+# the two measured constants of bench.py's roofline.serial_bound (stamp build of the same sources + the empty-launch period)
+timeout -k 10 400 python3 scripts/serial_bound.py $tag > $out/serial_bound.json 2> $out/serial_bound.err || echo "serial_bound failed"
+echo "serial bound: $(cut -c1-200 $out/serial_bound.json)"
+# larger and smaller launches of the same workload (bench.py attaches them to the default line as roofline.larger_batches);
+# taken BEFORE the default line so that it can quote them
+for n in 32768 131072 262144; do
+  timeout -k 10 300 python3 bench.py --envs-per-gpu $n --no-cpu-baseline > profiles/${tag}_bench_config2_n$n.json 2> $out/bench_n$n.err
+  echo "bench n=$n: $(cut -c1-120 profiles/${tag}_bench_config2_n$n.json)"
+done
+# cfg.scheme = 0 (ten RK4 substeps per interval: what rounds 1-4 shipped) on the same box, same workload
+timeout -k 10 300 python3 bench.py --scheme 0 --no-cpu-baseline > profiles/${tag}_bench_config2_scheme0.json 2> $out/bench_scheme0.err
+timeout -k 10 300 python3 bench.py --scheme 0 --workload config5 --no-cpu-baseline > profiles/${tag}_bench_config5_scheme0.json 2>> $out/bench_scheme0.err
+timeout -k 10 300 python3 bench.py --scheme 0 --workload cycle --no-cpu-baseline > profiles/${tag}_bench_cycle_scheme0.json 2>> $out/bench_scheme0.err
+echo "bench scheme 0: $(cut -c1-120 profiles/${tag}_bench_config2_scheme0.json)"
 for w in config2 config1 config5 cycle; do
   timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
   cp $out/bench_$w.json profiles/${tag}_bench_$w.json

@@ -81,3 +81,30 @@ def test_reference_cpu_timing_file_is_what_bench_reports():
     assert 500 < rec["value"] < 1e4 and rec["script"] == "oracle/time_reference.py" and "NOT the GPU box" in rec["hardware"]
     assert abs(raw["one_process"]["episode_return_seed0"] - -0.8789670883455737) < 1e-12       # the reference's anchor, reproduced
     assert "REFERENCE_CPU" not in open(os.path.join(ROOT, "bench.py")).read()
+
+
+def test_serial_bound_constants_and_larger_batches_are_hash_matched_committed_records(tmp_path):
+    """VERDICT r4 items 2 and 6 / ADVICE r4: roofline.serial_bound's two measured constants and roofline.larger_batches come
+    from committed files keyed by the library they were measured on; a kernel edit makes them disappear instead of going stale."""
+    d = str(tmp_path)
+    h = B.source_hash()
+    flipped = h[:-1] + ("0" if h[-1] != "0" else "1")
+    with open(os.path.join(d, "r05_serial_bound.json"), "w") as f:
+        json.dump({"library_source_hash": h, "arithmetic_us": {"anoxic": 3.2, "aerobic": 4.9}, "dependent_launch_floor_us": 1.8}, f)
+    rec = bench.serial_bound_record(h, d)
+    assert rec["arithmetic_us"]["aerobic"] == 4.9 and rec["_file"].endswith("r05_serial_bound.json")
+    assert bench.serial_bound_record(flipped, d) is None and bench.serial_bound_record(None, d) is None
+    for n, hh in ((131072, h), (262144, flipped)):
+        with open(os.path.join(d, "r05_bench_config2_n%d.json" % n), "w") as f:
+            json.dump({"value": 6e9, "ms_per_step": 0.02, "roofline": {"frac": 0.4},
+                       "config": {"envs_per_gpu": n, "library_source_hash": hh}}, f)
+    lb = bench.larger_batches(h, d)
+    assert list(lb) == ["131072"] and lb["131072"]["frac"] == 0.4 and lb["131072"]["us_per_launch"] == 20.0
+    assert bench.larger_batches(flipped, d).keys() == {"262144"} and bench.larger_batches(None, d) is None
+    # no literal of the old kind is left in bench.py
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"arithmetic_us": 6.3' not in src and "1.82" not in src
+    # the committed record of this round, if it is of the current sources, has the shape bench.py reads
+    cur = bench.serial_bound_record(h)
+    if cur is not None:
+        assert set(cur["arithmetic_us"]) == {"anoxic", "aerobic"} and 0.5 < cur["dependent_launch_floor_us"] < 5

@@ -15,10 +15,11 @@ from gym_sbr2_amd import build as B
 K_STEP = "_Z6k_stepIffLi256ELb0ELi1EE"       # k_step<float, float, 256, false, 1>: the kernel bench.py times (scheme 1)
 K_STEP_SMALL = "_Z6k_stepIffLi64ELb0ELi1EE"    # the 64-thread-workgroup build used up to 49152 envs
 K_STEP_RK4 = "_Z6k_stepIffLi256ELb0ELi0EE"   # cfg.scheme = 0: ten RK4 substeps per interval
-K_ROLLOUT = "_Z9k_rolloutILb0ELi1EE"
-K_ROLLOUT_RK4 = "_Z9k_rolloutILb0ELi0EE"
-K_CYCLE = "_Z7k_cycleIffLi1EE"
-K_CYCLE_RK4 = "_Z7k_cycleIffLi0EE"
+K_ROLLOUT = "_Z9k_rolloutILb0ELi1ELi1EE"      # k_rollout<false, 1, 1>: scheme 1, register budget for one wave per SIMD
+K_ROLLOUT_2W = "_Z9k_rolloutILb0ELi1ELi2EE"
+K_ROLLOUT_RK4 = "_Z9k_rolloutILb0ELi0ELi2EE"
+K_CYCLE = "_Z7k_cycleIffLi1ELi1EE"
+K_CYCLE_RK4 = "_Z7k_cycleIffLi0ELi2EE"
 K_RESET = "_Z7k_resetIfLb0EE"
 K_RESET_CARRY = "_Z7k_resetIfLb1EE"
 K_CYCLE_RESET = "_Z13k_cycle_resetIfLb0EE"
@@ -66,6 +67,22 @@ def inner_loops(text):
     return [[x for x in lines[a:b + 1] if not x.endswith(":")] for a, b in inner]
 
 
+def all_loops(text):
+    """[(instruction list)] of EVERY loop (one per backward branch, label to branch), nested or not."""
+    lines = []
+    for raw in text.split("\n"):
+        l = raw.split(";")[0].strip()
+        if l and (l.endswith(":") or not l.startswith(".")):
+            lines.append(l)
+    label = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+    out = []
+    for i, l in enumerate(lines):
+        m = re.match(r"s_(?:cbranch_\w+|branch)\s+(\.LBB\S+)", l)
+        if m and m.group(1) in label and label[m.group(1)] < i:
+            out.append([x for x in lines[label[m.group(1)]:i + 1] if not x.endswith(":")])
+    return out
+
+
 def f64_mix(ins):
     c = collections.Counter(i.split()[0] for i in ins)
     return {"fma": c["v_fma_f64"] + c["v_fmac_f64_e32"], "mul": c["v_mul_f64"], "add": c["v_add_f64"], "rcp": c["v_rcp_f64_e32"],
@@ -73,17 +90,19 @@ def f64_mix(ins):
 
 
 def meta(asm, symbol, key):
-    m = re.search(r"\.name:\s+%s\S*\n(?:.*\n){0,20}?\s+\.%s:\s+(\d+)" % (re.escape(symbol), key), asm)
-    if m is None:      # the key may precede .name inside the kernel's metadata map
-        blk = re.search(r"(- \.agpr_count.*?\.name:\s+%s\S*\n.*?\.wavefront_size:\s+\d+)" % re.escape(symbol), asm, re.S)
-        m = re.search(r"\.%s:\s+(\d+)" % key, blk.group(1)) if blk else None
-    assert m, (symbol, key)
-    return int(m.group(1))
+    """A field of the kernel's entry in the code object's metadata (amdhsa.kernels).  The entries are YAML maps whose keys are
+    sorted, so some precede `.name` and some follow it: take the whole entry (it starts at `  - .agpr_count:`)."""
+    for blk in re.split(r"\n  - (?=\.agpr_count:)", asm[asm.index("amdhsa.kernels:"):]):
+        if re.search(r"\.name:\s+%s\S*\n" % re.escape(symbol), blk):
+            m = re.search(r"^\s+\.%s:\s+(\d+)" % key, "\n    " + blk, re.M)
+            assert m, (symbol, key)
+            return int(m.group(1))
+    raise AssertionError((symbol, "not in the metadata"))
 
 
 def test_rk4_substep_loops_have_the_quoted_instruction_mix(asm):
     import bench
-    loops = inner_loops(kernel_text(asm, K_STEP))
+    loops = inner_loops(kernel_text(asm, K_STEP_RK4))             # cfg.scheme = 0
     rk4 = [f64_mix(l) for l in loops if f64_mix(l)["rcp"] == 8 and f64_mix(l)["fma"] > 250]     # unrolled by two: 8 reciprocals
     # (the Butcher-5 step loops of scheme 1 hold 5 reciprocals: test_butcher5_step_loops below)
     assert len(rk4) >= 2
@@ -103,18 +122,31 @@ def test_rk4_substep_loops_have_the_quoted_instruction_mix(asm):
 
 def test_butcher5_step_loops(asm):
     """cfg.scheme = 1 (round 5): the step loops of the adaptive Butcher-5 integrator (sbr_b5a) - one per form (closed reactor /
-    carbon dosing in scaled-mass variables) and interval copy.  Nothing but arithmetic inside: no division, no lane operation,
-    no scratch, no AGPR traffic; <= 450 instructions per step without dosing, <= 500 with (measured 444 / 495): a six-stage
-    step costs what 1.6 RK4 substeps cost and replaces 2.5 to 10 of them."""
-    for k in (K_STEP, K_ROLLOUT):
-        loops = inner_loops(kernel_text(asm, k))
-        b5 = [l for l in loops if f64_mix(l)["rcp"] == 5 and f64_mix(l)["fma"] > 250]
-        assert len(b5) >= 2, k
-        sizes = sorted(len(l) for l in b5)
-        assert sizes[0] <= 450 and sizes[-1] <= 500, (k, sizes)
-        for l in b5:
+    carbon dosing in scaled-mass variables) and inlined copy.  A step is the loop from its head to the back edge that follows the
+    next step's first stage (a shorter back edge, taken when no lane needs another step, skips that stage): six right-hand sides,
+    <= 510 instructions without dosing and <= 570 with (measured 502 / 560; an RK4 substep has four and 272 / 297), nothing
+    but arithmetic: no division, no lane operation, no scratch.  bench.py's FP64_FLOP_PER_B5_STEP are these
+    loops' counts (FMA = 2)."""
+    import bench
+    for k in (K_STEP, K_ROLLOUT, K_CYCLE):
+        steps = [l for l in all_loops(kernel_text(asm, k)) if f64_mix(l)["rcp"] == 6 and len(l) < 575 and f64_mix(l)["lane"] == 0]
+        assert len(steps) >= (1 if k == K_CYCLE else 2), k
+        flop = sorted({m["fma"] * 2 + m["mul"] + m["add"] + m["rcp"] for m in map(f64_mix, steps)})
+        assert flop[0] == bench.FP64_FLOP_PER_B5_STEP["plain"], (k, flop)
+        if k != K_CYCLE:
+            assert flop[-1] == bench.FP64_FLOP_PER_B5_STEP["dosing"], (k, flop)
+        for l in steps:
             m = f64_mix(l)
-            assert m["div"] == 0 and m["lane"] == 0 and m["scratch"] == 0 and not any("accvgpr" in i for i in l), k
+            assert len(l) <= (510 if m["fma"] < 320 else 570), (k, len(l))
+            assert m["div"] == 0 and m["scratch"] == 0, k
+        # no AGPR traffic inside the step loops of the first (ordinary) control interval; the out-of-line copy for the second
+        # interval of a phase-boundary call (3 calls per episode) may hold a few moves
+        assert sum(1 for l in steps if not any("accvgpr" in i for i in l)) >= (1 if k == K_CYCLE else 2), k
+    # the scheme-1 kernels carry no RK4 loop for the control intervals (k_step's only RK4 is gone with the idle phase; k_cycle
+    # keeps the fill phase's), the scheme-0 kernels are what rounds 1-4 shipped
+    rk4 = lambda k: [l for l in inner_loops(kernel_text(asm, k)) if f64_mix(l)["rcp"] == 8 and f64_mix(l)["fma"] > 250]   # noqa: E731
+    assert len(rk4(K_STEP)) == 0 and len(rk4(K_ROLLOUT)) == 0 and len(rk4(K_STEP_RK4)) >= 2 and len(rk4(K_ROLLOUT_RK4)) >= 2
+    assert len(instructions(kernel_text(asm, K_STEP))) < 0.8 * 11200      # 7 614 instructions; 11 142 with both schemes in one kernel
 
 
 def test_k_step_has_no_scratch_no_division_on_the_ordinary_path(asm):
@@ -127,8 +159,10 @@ def test_k_step_has_no_scratch_no_division_on_the_ordinary_path(asm):
     # so k_step needs more than 256 registers (measured 292, the excess parked in AGPRs OUTSIDE the step loops) and one wave is
     # resident per SIMD.  At the bench's 65 536 envs (1 024 waves on 1 024 SIMDs) that is the occupancy anyway; launches of
     # 131 072 envs and more lose the overlap of two resident waves (DESIGN.md section 5 has the measured price).
-    assert meta(asm, K_STEP, "vgpr_count") <= 320
-    assert meta(asm, K_CYCLE, "vgpr_count") <= 256
+    assert meta(asm, K_STEP, "vgpr_count") <= 336
+    assert meta(asm, K_STEP_RK4, "vgpr_count") <= 256 and meta(asm, K_STEP_RK4, "private_segment_fixed_size") == 0    # scheme 0: as shipped in round 4
+    assert meta(asm, K_CYCLE_RK4, "vgpr_count") <= 256 and meta(asm, K_ROLLOUT_2W, "vgpr_count") <= 256
+    assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") == 0 and meta(asm, K_CYCLE, "private_segment_fixed_size") == 0
     small = f64_mix(instructions(kernel_text(asm, K_STEP_SMALL)))
     assert small["scratch"] == 0 and small["div"] <= 8 and meta(asm, K_STEP_SMALL, "private_segment_fixed_size") == 0
 
@@ -144,8 +178,67 @@ def test_secondary_kernels_carry_no_ieee_divisions(asm):
     """the k_step recipe applied to the per-cycle kernel and the resets.  Wave-uniform quotients (phase
     schedule, 1/(n td), So_sat/1800) are taken on the host with the reference's own operations, per-lane ones go through
     ONE reciprocal (the 13 flow-weighted influent means, the five effluent particulates, the reset observation's blend)."""
-    assert f64_mix(instructions(kernel_text(asm, K_CYCLE)))["div"] <= 6           # measured 0 (round 2: 26)
+    assert f64_mix(instructions(kernel_text(asm, K_CYCLE)))["div"] <= 6 and f64_mix(instructions(kernel_text(asm, K_CYCLE_RK4)))["div"] <= 6   # measured 0 (round 2: 26)
     for k in (K_RESET, K_RESET_CARRY):
         assert f64_mix(instructions(kernel_text(asm, k)))["div"] <= 4, k         # measured 0 (round 2: 19 / 20)
     assert f64_mix(instructions(kernel_text(asm, K_CYCLE_RESET)))["div"] <= 4     # measured 2 (round 2: 15)
     assert meta(asm, K_ROLLOUT, "vgpr_count") <= 320
+
+
+def _lines_with_comments(text):
+    out = []
+    for raw in text.split("\n"):
+        l = raw.split(";")[0].strip()
+        if l and not l.startswith(".") and not l.endswith(":"):
+            out.append(l)
+    return out
+
+
+VALU_PREFIX = ("v_",)       # everything the vector ALU executes; VMEM (global_/buffer_/scratch_), LDS (ds_), SALU (s_) are not
+
+
+@pytest.mark.parametrize("kernel", [K_STEP, K_STEP_SMALL, K_STEP_RK4, K_ROLLOUT, K_CYCLE])
+def test_inline_asm_invariants(asm, kernel):
+    """what makes the hand-written assembly of the stepping kernels safe is asserted, not left to convention.
+    Inline assembly is invisible to the compiler's hazard recognizer, so a refactor can silently reintroduce:
+      (a) a VALU instruction right behind a 16-byte store - on gfx940+ a VMEM store of more than 64 bits keeps reading its data
+          registers for two more cycles (round 4: the next store's address arithmetic overwrote them; `s_nop 1` in st_out16);
+      (b) an SGPR that a VALU instruction wrote (v_readlane) used as the address of an asm store (round 4, the unshipped
+          paired-rows patch: a memory-access fault) - every asm store uses the VGPR-address form `..., off`;
+      (c) a kernarg warm-up load (SBR_WARM_LINES) past the end of the kernel's argument segment."""
+    text = kernel_text(asm, kernel)
+    ins = _lines_with_comments(text)
+    wide_sc1 = [i for i, l in enumerate(ins) if l.startswith("global_store_dwordx4") and "sc1" in l]
+    if kernel in (K_STEP, K_STEP_SMALL, K_STEP_RK4):
+        assert len(wide_sc1) >= 9                      # the output rows leave as 16-byte write-through stores
+    for i in wide_sc1:
+        nxt = ins[i + 1]
+        assert nxt.startswith("s_nop") or not nxt.startswith(VALU_PREFIX), (kernel, ins[i], nxt)         # (a)
+        ops = [o.strip() for o in ins[i].split(None, 1)[1].split(",")]
+        assert ops[0].startswith("v") and ops[2].split()[0] == "off", (kernel, ins[i])                     # (b)
+    # every s_nop-guarded pair really is `store ; s_nop 1` (the asm statement was not split by an edit)
+    assert all(ins[i + 1] == "s_nop 1" for i in wide_sc1), kernel
+    # (c) the warm-up: a run of >= 20 consecutive s_load_dword into one register with 0x40-spaced literal offsets
+    seg = meta(asm, kernel, "kernarg_segment_size")
+    warm = []
+    for l in ins:
+        m = re.match(r"s_load_dword (s\d+), (s\[\d+:\d+\]), (0x[0-9a-f]+)$", l)
+        warm.append((m.group(1), int(m.group(3), 16)) if m else None)
+    runs, cur = [], []
+    for w in warm:
+        if w is not None and (not cur or w[0] == cur[-1][0]):
+            cur.append(w)
+        else:
+            if len(cur) >= 20:
+                runs.append(cur)
+            cur = [w] if w is not None else []
+    if len(cur) >= 20:
+        runs.append(cur)
+    if kernel in (K_STEP, K_STEP_SMALL, K_STEP_RK4):
+        assert len(runs) == 1, (kernel, len(runs))
+        offs = [o for _, o in runs[0]]
+        assert max(offs) + 4 <= seg, (max(offs), seg)                     # inside the segment ...
+        assert (max(offs) // 64) == ((seg - 1) // 64)                      # ... and its last 64-byte line is touched
+        assert {o // 64 for o in offs} >= set(range(1, (seg - 1) // 64 + 1))   # every line but the preloaded first one
+    else:
+        assert not runs
