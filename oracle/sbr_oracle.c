@@ -447,7 +447,8 @@ static void reset_from(const sbro_params* p, sbro_env* e, const double* influent
     const int n_rows = (int)((t_end - 0) / p->dt);      /* 252 */
     double x0c[NX];
     memcpy(x0c, e->x, sizeof x0c);
-    rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);
+    if (p->scheme == 1) b5a_span(p, 1, e->x, t_end, (n_rows + 9) / 10, kla, 0, e->influent);     /* ceil(rows / 10) macro intervals */
+    else rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);
     e->so_m2 = x0v[8]; e->so_m1 = e->x[8];
     e->sno_m2 = x0v[9]; e->sno_m1 = e->x[2];          /* :1652 stores Ss in the Sno memory */
     e->t = t_end;

@@ -186,8 +186,9 @@ def rk4_reaction_w(x, t0, t1, n, kla, ec):
 #     reaches (consumption slows as So falls, so the projection bounds So from below and z from above);
 #   * in the last case - the knee, where So moves through K_OH - n = max(4, floor(lam(0) span / 3.0) + 1): the worst-case
 #     lam(0) h stays below 3.0 (Butcher-5 is stable on the real axis up to 3.39; the reference plant never needs more than 4);
-#   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) is cut into ceil(rows/10) macro intervals, each
-#     planned like a control interval.
+#   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) and the fill phase of reset() (:1585-1654, one
+#     odeint over 252 dt, right-hand side filling_dxdt) are cut into ceil(rows/10) macro intervals, each planned like a control
+#     interval.
 # oracle/sbr_oracle.c b5a_interval does the same operations in the same order (bit-identical, tests/test_oracle_golden.py).
 B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB, B5A_N_MAX = 1e-9, 0.3, 1.0, 3.0, 64
 _A21, _A31, _A32, _A42, _A43, _A51, _A54 = 0.25, 0.125, 0.125, -0.5, 1.0, 3.0 / 16.0, 9.0 / 16.0
@@ -332,6 +333,8 @@ class SbrOsRef:
             return x1, None
         if f is rhs_idle and self.scheme == 1:
             return b5a_span(2, x, t1 - t0, (n_sub + 9) // 10, args[0])[0], None
+        if f is rhs_fill and self.scheme == 1:
+            return b5a_span(1, x, t1 - t0, (n_sub + 9) // 10, args[0], 0.0, args[1])[0], None
         if f is rhs_reaction and args[1] != 0:          # a dosing interval: RK4 on the scaled-mass system (rk4_reaction_w)
             return rk4_reaction_w(x, t0, t1, n_sub, *args), None
         return rk4(f, x, t0, t1, n_sub, args), None

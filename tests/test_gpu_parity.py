@@ -138,11 +138,11 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
     E, env, ora, acts, obs0, oobs0, ncall = _run_golden_batch(G, tables, torch.float64)
     n = len(E)
     x, ctrl = env.get_state()
-    assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6                    # post-fill, measured 9.7e-10
-    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0     # vs reference, measured 1.6e-3
+    assert gate(_np(x).T, ora.envs["x"]).max() < 1e-5                    # post-fill, measured 1.3e-6 (scheme 0: 9.7e-10)
+    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0     # vs reference, measured 0.09 (scheme 0: 1.6e-3)
     assert np.abs(obs0 - oobs0).max() < 1e-11                            # measured 4.4e-15
-    for i, e in enumerate(E):
-        assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6
+    for i, e in enumerate(E):        # the reset observation inherits the state gate over its normalisers (conftest.obs_tolerance)
+        assert np.all(np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= obs_tolerance(e["x_postfill"])[0] + 1e-12)
     T = [golden("sbros_%s_tight" % name) for name in EPISODES]      # the reference itself at odeint rtol = atol = 1e-12
     worst_gold, worst_tight = np.zeros(n), np.zeros(n)
     for c in range(ncall):
@@ -296,7 +296,7 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
     x, _ = env.get_state()
     assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0         # fill phase vs the reference, every scenario
     for i, e in enumerate(E):
-        assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6
+        assert np.all(np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= obs_tolerance(e["x_postfill"])[0] + 1e-12)
     worst_tight, worst_gold = np.zeros(n), np.zeros(n)
     xd, cd = env.get_state()
     for c in range(ncall):
@@ -363,7 +363,7 @@ def test_config2_4096_envs_full_episode_against_oracle(G, tables):
     oobs = free.reset(infl); sync.reset(infl)
     assert np.abs(obs - oobs).max() < 1e-5                            # float32 outputs
     x, ctrl = env.get_state()
-    assert gate(_np(x).T, free.envs["x"]).max() < 1e-6                # post-fill (252 substeps, open loop)
+    assert gate(_np(x).T, free.envs["x"]).max() < 1e-5                # post-fill (26 macro intervals of the adaptive scheme, open loop)
     ret = np.zeros(n); free_gate = []; worst_sync_ok = 0.0; worst_sync_flagged = 0.0
     odd = (np.arange(n) % 2 == 1)
     for c in range(ncall):
@@ -393,7 +393,7 @@ def test_config2_4096_envs_full_episode_against_oracle(G, tables):
         assert np.array_equal(cn[_capi.C_T], sync.envs["t"])
         assert np.abs(cn[_capi.C_KLA_LAST] - sync.envs["kla_last"]).max() < 1e-9           # computed before the integration:
         assert np.abs(cn[_capi.C_EC_LAST] - sync.envs["ec_last"]).max() < 1e-15            # tight for every env
-        assert np.abs(cn[_capi.C_IE_DO] - sync.envs["ie_do"]).max() < 1e-15 and np.abs(cn[_capi.C_IE_EC] - sync.envs["ie_ec"]).max() < 1e-15
+        assert np.abs(cn[_capi.C_IE_DO] - sync.envs["ie_do"]).max() < 1e-14 and np.abs(cn[_capi.C_IE_EC] - sync.envs["ie_ec"]).max() < 1e-14
         assert np.abs(cn[_capi.C_RETURN] - sync.envs["ret"])[ok].max() < 1e-12
         # --- free run
         if c < ncall - 1:
@@ -1075,7 +1075,8 @@ def test_reference_shaped_single_env(G):
     env = G.make("SBROS-v1")
     obs = env.reset(rnd=e["rnd"])
     assert isinstance(obs, tuple) and len(obs) == 2 and len(obs[0]) == 9 and len(obs[1]) == 9
-    assert np.allclose(obs[0], e["reset_obs_DO"], rtol=0, atol=1e-6) and np.allclose(obs[1], e["reset_obs_EC"], rtol=0, atol=1e-6)
+    tol0 = obs_tolerance(e["x_postfill"])[0] + 1e-12          # the state gate over the observation's normalisers
+    assert np.all(np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= tol0)
     total, done, k = 0.0, False, 0
     while not done:
         obs, state, reward, done, info = env.step([2.0, 5.0])
@@ -1093,9 +1094,11 @@ def test_reference_shaped_single_env(G):
     assert np.abs(np.array(reward_t) - e["step_reward"]).max() < 5e-7 and abs(sum(reward_t) - total) < 1e-12
     # the four diagnostics module_reward_EQIOCI.py:109-112 appends per call, against the reference's own lists
     assert np.abs(np.array(reward_EQI_t) - e["step_r_EQI2"]).max() < 5e-7 * max(1.0, np.abs(e["step_r_EQI2"]).max())
-    assert np.abs(np.array(reward_OCI_t) - e["step_r_OCI2"]).max() < 5e-7
-    assert np.abs(np.array(reward_AE_t) - e["step_r_AE2"]).max() < 5e-7
-    assert np.abs(np.array(reward_EC_t) - e["step_r_EC2"]).max() < 5e-7
+    # (OCI2 = cost terms over their maxima: EC / EC_max carries Kc = 100 times Sno's deviation where the PID is unsaturated)
+    assert np.abs(np.array(reward_OCI_t) - e["step_r_OCI2"]).max() < 5e-6
+    # (likewise Kla / Kla_max: Kc = 100 times So's deviation, a fifth of a gate = 1.6e-5 -> 7e-6 of the maximum; measured 9.6e-7)
+    assert np.abs(np.array(reward_AE_t) - e["step_r_AE2"]).max() < 5e-6
+    assert np.abs(np.array(reward_EC_t) - e["step_r_EC2"]).max() < 5e-6
     assert gate(x_t[:462], e["step_x_end"][:462]).max() <= 1.0 and np.array_equal(np.array(So_t), x_t[:, 8])
     # closed loop against the reference's default-tolerance run: the NO3-PID's integral sums (Sno - u_EC) dt, so it carries
     # the gate-level (1e-5) differences of Sno (<= 466 x 3e-4 x dt ~ 1.2e-5; measured 4.2e-8); EC itself is saturated at a
@@ -1190,7 +1193,9 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
         env.step(e["actions"][k])
     d2 = env.trajectory(as_dict=True, dense=True)
     assert np.array_equal(d2["x_t"][0], x_end)
-    assert np.allclose(d2["x_t"][251], env._x_postfill, rtol=1e-9, atol=1e-12)       # the replayed fill ends where the device's did
+    # the replayed fill (RK4 nodes, sbr_eval_substeps) ends where the device's did: to rounding under cfg.scheme = 0, within the
+    # two discretisations' distance under scheme 1 (the fill phase then takes 26 adaptive macro intervals)
+    assert gate(d2["x_t"][251], env._x_postfill).max() < 0.2
     assert abs(d2["x_t"][251][0] - 1.32) < 1e-12 and len(d2["t_t"]) == 252 + int((rows[:3] - 1).sum())
     assert np.abs(d2["x_t"][-1] - env.trajectory(as_dict=True)["x_t"][2]).max() < 1e-9
     # the lists that are per call upstream too are untouched by dense=True
@@ -1216,7 +1221,7 @@ def test_dense_trajectory_on_the_reference_output_grid(G, name):
     dt_ = 0.002 / 24
     tol_dcv = (tol_sno + np.concatenate([[tol_sno[0]], tol_sno[:-1]])) / dt_
     assert (np.abs(np.array(d["dcv_EC"][1:]) - e["traj_dcv_EC"][1:]) <= tol_dcv).all()
-    assert abs(d["dcv_EC"][1] - e["traj_dcv_EC"][1]) < 1e-6 * abs(e["traj_dcv_EC"][1])   # (Ss after the fill - x0[9]) / dt: the :1652 quirk
+    assert abs(d["dcv_EC"][1] - e["traj_dcv_EC"][1]) < 1e-5 * abs(e["traj_dcv_EC"][1])   # (Ss after the fill - x0[9]) / dt: the :1652 quirk (Ss to the gate)
     # the boundary calls contribute two entries: entry k of the lists belongs to interval k - 1 = (call iv_call[k - 1])
     two = np.nonzero(e["step_n_intervals"] == 2)[0]
     assert len(two) == 3
@@ -1618,7 +1623,8 @@ def test_numpy_rng_reset_is_the_reference_draw(G, monkeypatch):
     np.random.seed(0)
     env = G.make("SBROS-v1")
     obs = env.reset()                                           # no rnd=, no seed=
-    assert np.allclose(obs[0], e["reset_obs_DO"], rtol=0, atol=1e-6) and np.allclose(obs[1], e["reset_obs_EC"], rtol=0, atol=1e-6)
+    tol0 = obs_tolerance(e["x_postfill"])[0] + 1e-12          # the state gate over the observation's normalisers
+    assert np.all(np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= tol0)
     assert np.abs(env._influent[1:] - e["influent_mixed"][1:]).max() < 1e-11          # the reference's influent of seed 0
     after = np.random.get_state()[1].copy()
     np.random.seed(0); np.random.randn(48); np.random.randn(48)                        # the reference draws twice for scenario 6

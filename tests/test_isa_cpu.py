@@ -20,8 +20,9 @@ K_ROLLOUT_2W = "_Z9k_rolloutILb0ELi1ELi2EE"
 K_ROLLOUT_RK4 = "_Z9k_rolloutILb0ELi0ELi2EE"
 K_CYCLE = "_Z7k_cycleIffLi1ELi1EE"
 K_CYCLE_RK4 = "_Z7k_cycleIffLi0ELi2EE"
-K_RESET = "_Z7k_resetIfLb0EE"
-K_RESET_CARRY = "_Z7k_resetIfLb1EE"
+K_RESET = "_Z7k_resetIfLb0ELi1EE"
+K_RESET_CARRY = "_Z7k_resetIfLb1ELi1EE"
+K_RESET_RK4 = "_Z7k_resetIfLb0ELi0EE"
 K_CYCLE_RESET = "_Z13k_cycle_resetIfLb0EE"
 
 
