@@ -316,6 +316,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--policy", default="physical", choices=["physical", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="issue every step launch eagerly (one ctypes call per step)")
     ap.add_argument("--scheme", type=int, default=None, choices=[0, 1],
                     help="cfg.scheme: 1 (library default) adaptive Butcher-5 per interval, 0 ten RK4 substeps (rounds 1-4)")
     args = ap.parse_args()
@@ -406,6 +407,39 @@ def main():
         acct["allgathers"] += 1 if dist_up else 0
         env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
 
+    # The step launches are issued as HIP-graph replays (chunks of <= 64 steps; sbr_step allocates nothing and synchronises
+    # nothing, so a run of steps is capturable - DESIGN.md section 2): one host call per chunk instead of one ctypes call per
+    # step.  With scheme 1 an anoxic call takes < 10 us on the GPU, and issuing 20 of them through Python took the host
+    # 5 .. 13 us per step depending on the box (round 5: a driver-style run came out host-bound at 14.2 us per step on a slow
+    # host, 11.1 on a fast one).  The captured launches are exactly the eager ones; --no-graphs issues them eagerly.
+    graphs = {}
+
+    def chunks(c0, m):
+        while m > 0:
+            r = c0 & 63
+            ln = min(m, 64 - r)
+            yield r, ln
+            c0 += ln; m -= ln
+
+    def issue_steps(c0, m):
+        for r, ln in chunks(c0, m):
+            g = graphs.get((r, ln))
+            if g is not None:
+                g.replay()
+            else:
+                for j in range(r, r + ln):
+                    env.step(pool_rows[j])
+
+    def capture_for(schedule):
+        """Capture (untimed; nothing executes during capture) a graph for every chunk the given (call index, count) segments
+        will issue."""
+        if args.no_graphs or fused:
+            return
+        for c0, m in schedule:
+            for r, ln in chunks(c0, m):
+                if (r, ln) not in graphs and ln > 1:
+                    graphs[(r, ln)] = env.capture_steps([pool_rows[j] for j in range(r, r + ln)])
+
     def run(k_steps, record):
         done = 0
         while done < k_steps:
@@ -424,9 +458,7 @@ def main():
             if fused:
                 env.rollout(m, policy_seed=77)
             else:
-                c0 = state["in_episode"]
-                for j in range(c0, c0 + m):
-                    env.step(pool_rows[j & 63])
+                issue_steps(state["in_episode"], m)
             if record:
                 e1.record()
                 seg_events.append((e0, e1, m))
@@ -459,6 +491,17 @@ def main():
     # torch process takes tens of milliseconds of host time during which the GPU idles and drops out of its steady clocks
     # (round 3, scripts/probes/rollout_sustained.py: the first 25 ms after such a gap run up to 24 % slower) - placed between
     # priming and timing, as it was, it undid the priming for every region shorter than ~30 ms.
+    # every chunk the run will issue: whole episodes (priming, long regions), the warm-up's W - 1 and 1 steps from call 0, the K
+    # timed steps from call W (all modulo the episode length)
+    sched, c = [(0, CALLS_PER_EPISODE)], 0
+    for m_ in (max(args.warmup - 1, 0), min(args.warmup, 1), args.steps):
+        left = m_
+        while left > 0:
+            take = min(left, CALLS_PER_EPISODE - c)
+            sched.append((c, take))
+            c = (c + take) % CALLS_PER_EPISODE
+            left -= take
+    capture_for(sched)
     gc.collect(); gc.disable()
     if dist_up:                                 # the first barrier of a process group is slow (lazy connection set-up): not
         fence()                                 # between priming and timing either
@@ -670,6 +713,8 @@ def main():
                    "allgather_bytes_per_rank": 4 * n_local if dist_up else 0,
                    "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",
                    "policy": args.policy,
+                   "step_issue": ("eager: one ctypes call per step" if (args.no_graphs or fused) else
+                                  "HIP-graph replays of <= 64 captured sbr_step launches (%d graphs)" % len(graphs)),
                    "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
                    "scheme": scheme, "library_source_hash": lib_hash,

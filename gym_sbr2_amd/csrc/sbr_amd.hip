@@ -81,6 +81,15 @@ SBR_DEV void st_out(T* p, T v) {
 #endif
 }
 typedef unsigned int sbr_u32x4 __attribute__((ext_vector_type(4)));
+// The output staging of k_step reuses the wave's LDS parking region (declared double[]) for rows of OutT and reads it back as
+// 16-byte chunks: accesses through these may_alias types are visible to alias analysis (round 4 saw the float32
+// staging stores hoisted over the parked double loads).  The compiler barriers at the call sites stay as defence in depth.
+typedef sbr_u32x4 __attribute__((may_alias)) sbr_u32x4_alias;
+typedef float __attribute__((may_alias)) sbr_f32_alias;
+typedef double __attribute__((may_alias)) sbr_f64_alias;
+template <typename T> struct SbrAliasOf;
+template <> struct SbrAliasOf<float> { using type = sbr_f32_alias; };
+template <> struct SbrAliasOf<double> { using type = sbr_f64_alias; };
 // The sc1 modifier has no builtin for a 16-byte store, hence inline assembly - and inline assembly is invisible to the
 // compiler's hazard recognizer: on gfx940+ a VMEM store of more than 64 bits reads its data registers for two more cycles, and a
 // VALU instruction that overwrites them inside that window corrupts the stored value (seen in round 4, once the stores were
@@ -426,7 +435,7 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
     char* wdst = reinterpret_cast<char*>(rows + (size_t)(l & ~63u) * NV);
     if (wide && (reinterpret_cast<uintptr_t>(wdst) & 15u) == 0) {
         asm volatile("" ::: "memory");                         // see store_rows2: the staging stores must not overtake the parked loads
-        OutT* mine = reinterpret_cast<OutT*>(stage + lane * RB);
+        typename SbrAliasOf<OutT>::type* mine = reinterpret_cast<typename SbrAliasOf<OutT>::type*>(stage + lane * RB);
 #pragma unroll
         for (int k = 0; k < NV; ++k) mine[k] = v[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -437,7 +446,7 @@ SBR_DEV void store_rows(OutT* __restrict__ rows /* out + i0*NV: first row of the
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int c = r * 64 + (int)lane;
-            if ((r + 1) * 64 <= CH || c < CH) ch[r] = *reinterpret_cast<const sbr_u32x4*>(stage + c * 16);
+            if ((r + 1) * 64 <= CH || c < CH) ch[r] = *reinterpret_cast<const sbr_u32x4_alias*>(stage + c * 16);
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -472,8 +481,8 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
         asm volatile("" ::: "memory");
         char* sa = stage;
         char* sb = stage + 64 * RA;
-        OutT* ma = reinterpret_cast<OutT*>(sa + lane * RA);
-        OutT* mb = reinterpret_cast<OutT*>(sb + lane * RBB);
+        typename SbrAliasOf<OutT>::type* ma = reinterpret_cast<typename SbrAliasOf<OutT>::type*>(sa + lane * RA);
+        typename SbrAliasOf<OutT>::type* mb = reinterpret_cast<typename SbrAliasOf<OutT>::type*>(sb + lane * RBB);
 #pragma unroll
         for (int k = 0; k < NA; ++k) ma[k] = va[k];
 #pragma unroll
@@ -485,12 +494,12 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
 #pragma unroll
         for (int r = 0; r < NRA; ++r) {
             const int c = r * 64 + (int)lane;
-            if ((r + 1) * 64 <= CA || c < CA) ca[r] = *reinterpret_cast<const sbr_u32x4*>(sa + c * 16);
+            if ((r + 1) * 64 <= CA || c < CA) ca[r] = *reinterpret_cast<const sbr_u32x4_alias*>(sa + c * 16);
         }
 #pragma unroll
         for (int r = 0; r < NRB; ++r) {
             const int c = r * 64 + (int)lane;
-            if ((r + 1) * 64 <= CB || c < CB) cb[r] = *reinterpret_cast<const sbr_u32x4*>(sb + c * 16);
+            if ((r + 1) * 64 <= CB || c < CB) cb[r] = *reinterpret_cast<const sbr_u32x4_alias*>(sb + c * 16);
         }
 #pragma unroll
         for (int r = 0; r < NRA; ++r) {
@@ -720,7 +729,10 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
         if (dn && p.terminal) CTRL(R_QW) = qw;
         meta_unpack(my[SBR_PK_META * 64], steps, status, was_done);
         st_out(&CTRL(R_RET), my[SBR_PK_RET * 64] + r);
-        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed, !dn));
+        // the m1i bit ("So[-1] / Sno[-1] are x[8] / x[9]") is claimed only by a call that RAN an interval: a call with
+        // n_new == 0 (t injected as NaN) writes nothing to the memories, so it leaves them where they were - rows stay rows
+        const bool m1i_new = dn ? false : (c.n_new > 0 ? true : !m1_rows);
+        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed, m1i_new));
         SBR_STAMP(10, false);                 // controller stores issued
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
@@ -748,7 +760,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
     SBR_STAMP(11, false);                     // reward / done stores issued
     const bool wide = __builtin_amdgcn_ballot_w64(true) == ~0ull;      // all 64 lanes of the wave hold an env
     char* stage = reinterpret_cast<char*>(wave_lds);
-    // both row sets fit the wave's staging region together when they are float32 (64 x (72 + 60) = 8448 of 13312 bytes)
+    // both row sets fit the wave's staging region together when they are float32 (64 x (72 + 60) = 8448 of the region's 10240 bytes: 20 slots x 512)
     constexpr bool kBoth = 64 * (SBR_NOBS + SBR_NSTATE) * (int)sizeof(OutT) <= NSLOT * 64 * (int)sizeof(double);
     if (kBoth && obs && state) {
         OutT o[SBR_NOBS], sv[SBR_NSTATE];
@@ -1292,7 +1304,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     CREATE_TRY(hipMemset(e->buf.ctrl, 0, R_NROWS * nb));
     CREATE_TRY(hipMemset(e->buf.infl, 0, SBR_NX * nb));
     // an env is unusable until its first reset: mark everything done so that step() is a no-op until then
-    // (meta = steps*32 + idle*16 + status*2 + done  =>  1.0 = "done"); filled on the device, no host staging buffer
+    // (meta = steps*64 + m1i*32 + idle*16 + status*2 + done  =>  1.0 = "done"); filled on the device, no host staging buffer
     hipLaunchKernelGGL(k_fill, grid_for(n_envs), dim3(SBR_BLOCK), 0, nullptr, e->buf.ctrl + (size_t)R_META * n_envs, n_envs, 1.0);
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipDeviceSynchronize());

@@ -234,7 +234,10 @@ int sbr_rollout(sbr_env* env, int32_t n_steps, uint64_t policy_seed, double* ret
  * + one atomic per wave.  out4 = {sum, min, max, count} float64, DEVICE pointer. */
 int sbr_reduce_stats(sbr_env* env, const double* values, int64_t n, double* out4, void* stream);
 
-/* parity injection / inspection: x is [SBR_NX][N], ctrl is [SBR_NCTRL][N], float64, DEVICE pointers. */
+/* parity injection / inspection: x is [SBR_NX][N], ctrl is [SBR_NCTRL][N], float64, DEVICE pointers.
+ * An injected volume x[0] is taken as it is.  The dosing integrator expands 1/(V/V0) to third order in Q t_delta / V0
+ * (sbr_create checks EC_max t_delta <= 1e-4 min(IV, WV), i.e. <= 7e-7 for the reference plant): a state injected with a
+ * volume below ~1 % of IV would carry a truncation (Q t_delta / V0)^4 above 1e-16 into its dosing intervals. */
 int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
 int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
 

@@ -47,6 +47,13 @@ def test_native_library_is_loaded_and_fails_loudly_on_bad_config(G):
     assert lib.sbr_create(4, 0, 0, C.byref(cfg), C.byref(h)) == -1 and b"t_delta" in lib.sbr_last_error(None)
     assert lib.sbr_create(0, 0, 0, None, C.byref(h)) == -1
     assert lib.sbr_create(4, 99, 0, None, C.byref(h)) == -1
+    # the guard of the dosing integrator's 1/s series (EC_max * t_delta <= 1e-4 of the reactor volume) and the scheme
+    cfg = _capi.default_config(); cfg.EC_max = 2.0
+    assert lib.sbr_create(4, 0, 0, C.byref(cfg), C.byref(h)) == -1 and b"EC_max" in lib.sbr_last_error(None)
+    cfg = _capi.default_config(); cfg.EC_max = 1e-4 * cfg.IV / cfg.t_delta * 0.99
+    assert lib.sbr_create(4, 0, 0, C.byref(cfg), C.byref(h)) == 0 and lib.sbr_destroy(h) == 0
+    cfg = _capi.default_config(); cfg.scheme = 2
+    assert lib.sbr_create(4, 0, 0, C.byref(cfg), C.byref(h)) == -1 and b"scheme" in lib.sbr_last_error(None)
     env = G.SbrOSVec(4)
     with pytest.raises(ValueError):
         env.step(torch.zeros(3, 2))
@@ -1869,6 +1876,17 @@ def test_implicit_so_sno_memories_across_every_writer(G, tables):
                 assert np.allclose(cc[row], ora.envs[key], rtol=1e-9, atol=1e-12), key
         return xx, torch.from_numpy(cc).cuda()
 
+    # a call in which NO interval runs (t injected as NaN) straight after the reset must leave the memories where
+    # they are - Sno[-1] = Ss of the fill, held in the ROWS, not x[9] - and must not claim the implicit form
+    x0s, c0s = env.get_state()
+    c_nan = c0s.clone(); c_nan[_capi.C_T] = float("nan")
+    env.set_state(x0s, c_nan)
+    env.step(torch.zeros(n, 2, dtype=torch.float64, device="cuda"))
+    xn, cn = env.get_state()
+    assert torch.equal(xn, x0s)                                                                          # the plant did not move
+    assert torch.equal(cn[_capi.C_SNO_M1], x0s[2]) and torch.equal(cn[_capi.C_SO_M1], c0s[_capi.C_SO_M1])   # still the reset's values
+    assert not torch.equal(cn[_capi.C_SNO_M1], xn[9])
+    env.set_state(x0s, c0s)                        # back to the state after the reset (steps, return and time included)
     x, ctrl = lockstep(6)
     assert torch.equal(ctrl[_capi.C_SO_M1], x[8]) and torch.equal(ctrl[_capi.C_SNO_M1], x[9])          # implicit now
     # an import of memories that are not the plant's values: the next step must use THEM (the oracle gets the same rows)
