@@ -373,6 +373,8 @@ def main():
     cfg = _capi.default_config()
     if args.scheme is not None:
         cfg.scheme = args.scheme
+    elif args.workload == "config1":
+        cfg.scheme = 0                    # BASELINE.json words configs[1] as "fixed-step RK4"; --scheme 1 runs the default scheme on it
     scheme = int(cfg.scheme)
     cfg.act_DO_max = do_max               # what the fused rollout's on-device policy draws from (and clips to)
     # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK

@@ -344,9 +344,11 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
     env.close()
 
 
-def test_config2_4096_envs_full_episode_against_oracle(G, tables):
-    """BASELINE.json configs[1]: 4096 envs, fixed-step RK4, deterministic influent (rnd = 0), scenario = env id mod 8,
-    seeded random float32 actions; EVERY env on EVERY call (1.9 M env-calls), against the C oracle.
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_config2_4096_envs_full_episode_against_oracle(G, tables, scheme):
+    """BASELINE.json configs[1]: 4096 envs, fixed-step RK4 (cfg.scheme = 0, as the config words it; and the library's default
+    scheme 1), deterministic influent (rnd = 0), scenario = env id mod 8, seeded random float32 actions; EVERY env on EVERY call
+    (1.9 M env-calls), against the C oracle.
 
     Policy: even envs draw U[0,8] x U[0,15] every call (the aggressive case: both clamps, bang-bang dosing); odd envs
     draw the DO set-point from U[0,2.5].  The reference model has no guards and the aggressive policy drives
@@ -362,9 +364,10 @@ def test_config2_4096_envs_full_episode_against_oracle(G, tables):
     rs = np.random.RandomState(2)
     scen = (np.arange(n) % 8).astype(np.int32)
     rnd = np.zeros((n, 48))
-    env = G.SbrOSVec(n, out_dtype=torch.float32)
-    sync = O.OracleBatch(n, nthreads=8)
-    free = O.OracleBatch(n, nthreads=8)
+    cfg = _capi.default_config(); cfg.scheme = scheme
+    env = G.SbrOSVec(n, out_dtype=torch.float32, config=cfg)
+    sync = O.OracleBatch(n, O.default_params(scheme=scheme), nthreads=8)
+    free = O.OracleBatch(n, O.default_params(scheme=scheme), nthreads=8)
     obs = _np(env.reset(scenario=scen, rnd=rnd))
     infl = free.mix(means, stds, scen, rnd)
     oobs = free.reset(infl); sync.reset(infl)
