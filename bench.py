@@ -275,8 +275,8 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
             "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work"}
     if scheme == 1:       # the step count of every non-fill interval is decided per env; this path has no CPU sample to count them
         fp64 = {"achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "note": "cfg.scheme = 1: 504 of the 528 intervals take 1, 2 or 4 Butcher-5 steps (773 FLOP each) as each env's state "
-                        "demands, the 24 fill intervals ten RK4 substeps; read issue_slot_frac (committed PMC profile) for utilisation"}
+                "note": "cfg.scheme = 1: every one of the 528 intervals takes 1, 2 or 4 Butcher-5 steps (773 FLOP each) as each env's "
+                        "state demands; read issue_slot_frac (committed PMC profile) for utilisation"}
     rec, why = pmc_record(loaded_library_hash())
     traffic = None
     if rec and "cycle" in rec and n_local == rec.get("envs_per_launch", 65536):

@@ -2,8 +2,10 @@
 //
 // Kernels (all one-lane-per-env over SoA float64 state, 256-thread workgroups = four wavefronts, one per SIMD of a CU, so
 // a launch of N envs is N/64 independent waves that the dispatcher spreads over the 1024 SIMDs):
-//   k_reset    influent mix (tables in LDS) + fill phase (252 RK4 substeps) + controller init + obs
-//   k_step     one SbrOS.step(): phase logic, 2 PIDs, 10 RK4 substeps (x2 at phase boundaries), reward,
+//   k_reset    influent mix (tables in LDS) + fill phase (scheme 1: 26 adaptive macro intervals; scheme 0: 252 RK4 substeps) +
+//              controller init + obs
+//   k_step     one SbrOS.step(): phase logic, 2 PIDs, the interval's integration (cfg.scheme 1: adaptive Butcher-5 steps per lane,
+//              sbr_b5a; scheme 0: 10 RK4 substeps; x2 at phase boundaries), reward,
 //              obs/state, and the terminal phases on the last call of an episode
 //   k_rollout  n_steps fused step()s with an on-device Philox policy, plant state stays in VGPRs
 //   k_cycle_reset, k_cycle   the per-cycle env SBR-v2: one launch = one whole 12 h cycle (528 control intervals)
@@ -884,7 +886,8 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
     }
 }
 
-// SbrEnv2.step: one whole 12 h cycle per env (528 control intervals x 10 RK4 substeps) in one launch.
+// SbrEnv2.step: one whole 12 h cycle per env (528 control intervals; scheme 1: adaptive Butcher-5 steps, scheme 0: x 10 RK4
+// substeps) in one launch.
 template <typename OutT, typename ActT, int SCH, int WAVES>
 __global__ __launch_bounds__(SBR_BLOCK, WAVES) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {

@@ -1141,8 +1141,12 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, dou
         if (k > p.Kla_max) { k = p.Kla_max; ie = ie - e * p.cyc_dt; }
         if (k < p.Kla_min) { k = p.Kla_min; ie = ie - e * p.cyc_dt; }
         if (i == 0) bias = k;
-        if constexpr (SCH == 1 && !FILL) sbr_b5a<false>(p, x, g1 - g0, k, 0.0);     // scheme 1: every interval but the fill phase's
-        else sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
+        if constexpr (SCH == 1) {                                  // scheme 1: every interval by the adaptive steps
+            if constexpr (FILL) sbr_b5a_fill(p, x, g1 - g0, k, ld);
+            else sbr_b5a<false>(p, x, g1 - g0, k, 0.0);
+        } else {
+            sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
+        }
         sum = sum + k;
         so_prev = so; so = x[8];
     }

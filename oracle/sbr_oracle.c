@@ -757,7 +757,7 @@ static double cycle_phase(const sbro_params* p, double* x, double t_start, doubl
         if (k > p->Kla_max) { k = p->Kla_max; ie = ie - e * p->cyc_dt; }
         if (k < p->Kla_min) { k = p->Kla_min; ie = ie - e * p->cyc_dt; }
         if (i == 0) bias = k;
-        if (p->scheme == 1 && !loading) b5a_span(p, 2, x, g1 - g0, 1, k, 0, 0);     /* scheme 1: every interval but the fill phase's */
+        if (p->scheme == 1) b5a_span(p, loading ? 1 : 2, x, g1 - g0, 1, k, 0, loading);      /* scheme 1: every interval */
         else rk4_span(p, loading ? 1 : 2, x, g1 - g0, p->substeps, k, 0, loading);
         sum = sum + k;
         if (kla_log) kla_log[i] = k;

@@ -108,3 +108,24 @@ def test_serial_bound_constants_and_larger_batches_are_hash_matched_committed_re
     cur = bench.serial_bound_record(h)
     if cur is not None:
         assert set(cur["arithmetic_us"]) == {"anoxic", "aerobic"} and 0.5 < cur["dependent_launch_floor_us"] < 5
+
+
+def test_design_per_scenario_table_is_generated_from_the_committed_json():
+    """DESIGN.md 4.3.1 quotes worst gate and max lambda*dt PER SCENARIO; the table is generated by
+    scripts/analysis/scenario_gates.py from profiles/r05_scenario_gates.json (which that script computes from the fixtures and the
+    C oracle), and the figures themselves are inside the bars the parity tests assert."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scenario_gates", os.path.join(ROOT, "scripts", "analysis", "scenario_gates.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_scenario_gates.json")))
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    held = text[text.index(g.BEGIN) + len(g.BEGIN):text.index(g.END)].strip()
+    assert held == g.markdown(rec).strip()
+    assert set(rec["per_scenario"]) == {str(s) for s in range(8)} and len(rec["episodes"]) == 24
+    for s, v in rec["per_scenario"].items():
+        assert v["open"] <= 0.6 and v["open_s1"] <= 0.3 and v["closed_tight"] <= 0.6 and v["closed_tight_s1"] <= 0.5, (s, v)
+        assert v["lam_dt"] < 2.785 / 2.5                      # RK4 x 10: at least 2.5 x inside its stability interval everywhere
+    # the bench's own workload (physical policy on scenarios 4..7) stays inside the model's domain for the whole episode
+    assert all(rec["episodes"]["scn%d_phys" % s]["valid_calls"] == 463 and rec["episodes"]["scn%d_phys" % s]["domain_exit_call"] == -1
+               for s in (4, 5, 6, 7))

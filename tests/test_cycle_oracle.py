@@ -54,8 +54,7 @@ def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables):
 
 @pytest.mark.parametrize("scheme", [0, 1])
 def test_rk4_cycle_inside_gate_of_reference(tables, scheme):
-    """RK4 with 10 substeps per control interval (scheme 0) and the adaptive Butcher-5 of round 5 (scheme 1: every interval but
-    the fill phase's) against the reference's LSODA, closed loop over the whole cycle.
+    """RK4 with 10 substeps per control interval (scheme 0) and the adaptive Butcher-5 of round 5 (scheme 1: every interval) against the reference's LSODA, closed loop over the whole cycle.
     Measured: phase-end states <= 0.018 of the gate, rewards within 3.2e-8, Qw within 1.7e-7 relative (scheme 0)."""
     means, stds = tables
     g = golden("sbrv2_cycles")
