@@ -2,8 +2,7 @@
 //
 // Kernels (all one-lane-per-env over SoA float64 state, 256-thread workgroups = four wavefronts, one per SIMD of a CU, so
 // a launch of N envs is N/64 independent waves that the dispatcher spreads over the 1024 SIMDs):
-//   k_reset    influent mix (tables in LDS) + fill phase (scheme 1: 26 adaptive macro intervals; scheme 0: 252 RK4 substeps) +
-//              controller init + obs
+//   k_reset    influent mix (tables in LDS) + fill phase (252 RK4 substeps under either scheme) + controller init + obs
 //   k_step     one SbrOS.step(): phase logic, 2 PIDs, the interval's integration (cfg.scheme 1: adaptive Butcher-5 steps per lane,
 //              sbr_b5a; scheme 0: 10 RK4 substeps; x2 at phase boundaries), reward,
 //              obs/state, and the terminal phases on the last call of an episode
@@ -321,7 +320,7 @@ SBR_DEV int pick_scenario(const SbrPar& p, const int32_t* __restrict__ scenario,
 // ------------------------------------------------------------------------------------------- reset
 // SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
 // workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
-template <typename OutT, bool CARRY, int SCH>
+template <typename OutT, bool CARRY>
 __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
                                                     uint64_t seed, const int32_t* __restrict__ scenario,
                                                     const double* __restrict__ rnd, const double* __restrict__ influent,
@@ -364,12 +363,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
     double kla = p.Kc_DO * e + p.KcI_DO * ie;
     if (kla > p.Kla_max) { kla = p.Kla_max; ie = ie - e * p.dt; }
     if (kla < p.Kla_min) { kla = p.Kla_min; ie = ie - e * p.dt; }
-    if constexpr (SCH == 1) {                                        // ceil(rows / 10) macro intervals of the adaptive scheme
-#pragma unroll 1
-        for (int j = 0; j < (p.fill_rows + 9) / 10; ++j) sbr_b5a_fill(p, x, p.h_fill_b5, kla, ld);
-    } else {
-        sbr_rk4<2>(p, x, p.h_fill, p.fill_rows, kla, ld[0], ld);
-    }
+    sbr_rk4<2>(p, x, p.h_fill, p.fill_rows, kla, ld[0], ld);        // RK4 under either scheme (see sbr_cycle_phase)
     c.t = p.T_fill;
     c.so_m2 = x0[8]; c.so_m1 = x[8];
     c.sno_m2 = x0[9]; c.sno_m1 = x[2];                               // :1652 stores Ss in the Sno memory
@@ -544,7 +538,7 @@ SBR_DEV void store_rows2(OutT* __restrict__ rows_a, OutT* __restrict__ rows_b, u
 // k_step's argument segment: four pointers / sizes, the flags word (+ padding), four pointers, SbrPar, SbrBuf.  The touched
 // offsets must stay inside it (a scalar load past the segment may fault) and reach its last line.
 static constexpr size_t kStepKernargBytes = 72 + sizeof(SbrPar) + sizeof(SbrBuf);
-static_assert(kStepKernargBytes >= 0x548 + 4 && kStepKernargBytes <= 0x548 + 56,   // 0x558 with h_fill_b5: still the line of 0x548
+static_assert(kStepKernargBytes >= 0x548 + 4 && kStepKernargBytes <= 0x548 + 56,
               "SbrPar / SbrBuf changed size: adjust the offsets of SBR_WARM_LINES to cover k_step's argument segment");
 // In two halves, issue at wave start and wait after the wave's global loads have gone out: the scratch register stays allocated
 // (an in/out operand of the second statement) until the loads have landed, so the compiler cannot hand it to anything else
@@ -886,8 +880,8 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_cycle_reset(SbrPar p, SbrBu
     }
 }
 
-// SbrEnv2.step: one whole 12 h cycle per env (528 control intervals; scheme 1: adaptive Butcher-5 steps, scheme 0: x 10 RK4
-// substeps) in one launch.
+// SbrEnv2.step: one whole 12 h cycle per env (528 control intervals; scheme 1: adaptive Butcher-5 steps on all but the 24 fill
+// intervals, scheme 0: x 10 RK4 substeps) in one launch.
 template <typename OutT, typename ActT, int SCH, int WAVES>
 __global__ __launch_bounds__(SBR_BLOCK, WAVES) void k_cycle(SbrPar p, SbrBuf b, const ActT* __restrict__ action, OutT* __restrict__ obs,
                                                     OutT* __restrict__ reward, double* __restrict__ diag) {
@@ -1133,7 +1127,6 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     p.random_scenario = c.random_scenario;
     p.inv_dt = 1.0 / c.dt; p.inv_t_delta = 1.0 / c.t_delta; p.inv_substeps = 1.0 / (double)c.substeps;
     p.inv_cyc_dt = 1.0 / c.cyc_dt; p.h_fill = c.T_fill / (double)p.fill_rows;
-    p.h_fill_b5 = c.T_fill / (double)((p.fill_rows + 9) / 10);
     {   // module_reward_EQIOCI.py:72, :80 - Kla = 240 and EC = 0.0005 over eleven rows of its own t_delta = 0.002/24, So_sat = 8
         const double td = 0.002 / 24;
         p.inv_ae_max = 1.0 / (1.32 * (240 * 11) * td * (8 / ((td * 11) * 1.8 * 1000)));
@@ -1315,10 +1308,8 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     CREATE_TRY(hipEventCreate(&e->ev1));
     {
         const int lds_bytes = kLdsTableDoubles * (int)sizeof(double);      // 84 KiB of dynamic LDS: above the 64 KiB default
-        const void* fns[8] = {reinterpret_cast<const void*>(&k_reset<float, false, 0>), reinterpret_cast<const void*>(&k_reset<float, true, 0>),
-                              reinterpret_cast<const void*>(&k_reset<double, false, 0>), reinterpret_cast<const void*>(&k_reset<double, true, 0>),
-                              reinterpret_cast<const void*>(&k_reset<float, false, 1>), reinterpret_cast<const void*>(&k_reset<float, true, 1>),
-                              reinterpret_cast<const void*>(&k_reset<double, false, 1>), reinterpret_cast<const void*>(&k_reset<double, true, 1>)};
+        const void* fns[4] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
+                              reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>)};
         for (const void* fn : fns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         const void* cfns[4] = {reinterpret_cast<const void*>(&k_cycle_reset<float, false>), reinterpret_cast<const void*>(&k_cycle_reset<float, true>),
                                reinterpret_cast<const void*>(&k_cycle_reset<double, false>), reinterpret_cast<const void*>(&k_cycle_reset<double, true>)};
@@ -1364,13 +1355,11 @@ static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scen
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : kLdsTableDoubles * sizeof(double);
     const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
-#define RESET_LAUNCH1(T, C, S) hipLaunchKernelGGL((k_reset<T, C, S>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
-                                                  influent, mask, (T*)obs)
-#define RESET_LAUNCH(T, C) do { if (e->cfg.scheme == 1) RESET_LAUNCH1(T, C, 1); else RESET_LAUNCH1(T, C, 0); } while (0)
+#define RESET_LAUNCH(T, C) hipLaunchKernelGGL((k_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
+                                              influent, mask, (T*)obs)
     if (e->cfg.out_f64) { if (carry) RESET_LAUNCH(double, true); else RESET_LAUNCH(double, false); }
     else { if (carry) RESET_LAUNCH(float, true); else RESET_LAUNCH(float, false); }
 #undef RESET_LAUNCH
-#undef RESET_LAUNCH1
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

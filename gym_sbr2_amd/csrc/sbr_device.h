@@ -61,7 +61,6 @@ struct SbrPar {
     // reciprocals of wave-uniform divisors, taken once on the host (an IEEE f64 division is ~19 issue slots on the device)
     double inv_dt, inv_t_delta, inv_substeps, inv_cyc_dt, h_fill;
     double inv_Koh, inv_Koa;
-    double h_fill_b5;        // scheme 1: length of one macro interval of the fill phase, T_fill / ceil(fill_rows / 10)
     double inv_ae_max, inv_ec_max;   // 1 / AE_OCI_max, 1 / EC_OCI_max of module_reward_EQIOCI.py:72, :80 (trajectory export)
     // len(t_range) = int(span/dt) of a control interval (:1339, :1384) is 10 iff span >= rows10_min and 9 iff
     // rows9_min <= span < rows10_min: the smallest doubles whose IEEE quotient by dt reaches 10.0 / 9.0 (found on the
@@ -539,117 +538,6 @@ SBR_DEV void sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double k
     const double u = DOSE ? __builtin_fma(-n0, c14, x[13]) * rs : __builtin_fma(-n0, c14, x[13]);
     sbr_scatter(a, x);
     x[7] = xp;
-    x[13] = __builtin_fma(x[10] - x[9], c14, u);
-}
-// One macro interval of the FILL phase under scheme 1 (filling_dxdt :1424-1583 at EC = 0: conversion + (Q/V)(c_in - c), V' = Q,
-// Q = ld[0], c_in = ld[1..13]): the same plan and the same running-sum Butcher-5 steps as sbr_b5a, on TEN components - the nine
-// that feed the rates and Xp, whose inflow term depends on Xp itself - with Q/V taken afresh at every stage time (V is linear
-// in t).  Si, Xi and the charge balance u = Salk - (Snh - Sno)/14 only dilute: c(t1) = c0 + g (c_in - c0), g = (V1 - V0)/V1,
-// exactly, so they are closed once per macro interval.  (The oxygen rate of the plan leaves the dilution rate Q/V out: 25 - 55
-// per day against thousands.)
-SBR_DEV void sbr_b5a_fill(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, const double (&ld)[SBR_NX]) {
-    constexpr int NV = SBR_NA + 1;
-    const double kla_sat = kla * p.So_sat, Q = ld[0];
-    const double v0 = x[0], n0 = x[10] - x[9];
-    const SbrMonod m = sbr_monod(p, kla_sat);
-    const double lda[NV] = {ld[2], ld[4], ld[5], ld[6], ld[8], ld[9], ld[10], ld[11], ld[12], ld[7]};
-    double a[NV], k[NV];
-    {
-        double a9[SBR_NA];
-        sbr_gather(x, a9);
-#pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) a[i] = a9[i];
-        a[SBR_NA] = x[7];
-    }
-    double m_so = 1.0;
-    auto stage = [&](const double (&y)[NV], double t_st) {        // slopes of y at time t_st since the start of the macro interval
-        double y9[SBR_NA], k9[SBR_NA];
-        SbrRho o;
-#pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) y9[i] = y[i];
-        sbr_rates(p, m, y9, kla, k9, o);
-        k9[A_SNO] = k9[A_SNO] * p.n9_3;
-        const double q = Q * sbr_rcp(__builtin_fma(Q, t_st, v0));
-#pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) k[i] = __builtin_fma(q, lda[i] - y[i], k9[i]);
-        k[SBR_NA] = __builtin_fma(q, lda[SBR_NA] - y[SBR_NA], p.n7_45b * o.s45b);
-        k[A_SO] = k[A_SO] * m_so;
-    };
-    stage(a, 0.0);
-    // ---- the plan (as in sbr_b5a)
-    const double so = a[A_SO];
-    const double proj = __builtin_fma(k[A_SO], span, so);
-    const double lo1 = proj < so ? proj : so;
-    const double so_lo = lo1 > 0.0 ? lo1 : 0.0;
-    const double dh = p.Koh + so_lo, da = p.Koa + so_lo;
-    const double P1 = (p.Ks + a[A_SS]) * (dh * dh), P3 = (p.Knh + a[A_SNH]) * (da * da);
-    const double R = sbr_rcp(P1 * P3);
-    const double r1 = R * P3, r3 = R * P1;
-    const double c1 = (-p.n8_1 * p.muH) * (a[A_SS] * a[A_XBH]), c3 = (-p.n8_3 * p.muA) * (a[A_SNH] * a[A_XBA]);
-    const double z_ub = __builtin_fma(c1 * p.Koh, r1, __builtin_fma(c3 * p.Koa, r3, kla)) * span;
-    const double lam0 = __builtin_fma(c1 * p.inv_Koh, r1 * (dh * dh), __builtin_fma(c3 * p.inv_Koa, r3 * (da * da), kla));
-    const bool slaved = (fabs(so) < 1e-9) && (kla_sat * span < 1e-9);
-    const double qn = lam0 * span * (1.0 / 3.0);
-    const int n_knee = qn < 4.0 ? 4 : (!(qn < 64.0) ? 64 : (int)qn + 1);
-    const int n = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : n_knee));
-    m_so = slaved ? 0.0 : 1.0;
-    const double h = n == 1 ? span : (n == 2 ? span * 0.5 : (n == 4 ? span * 0.25 : span * sbr_rcp((double)n)));
-    k[A_SO] = k[A_SO] * m_so;
-    SbrB5C c;
-    c.a21 = h * 0.25; c.a31 = h * 0.125; c.a42 = h * -0.5; c.a51 = h * (3.0 / 16.0); c.a54 = h * (9.0 / 16.0);
-    c.a61 = h * (-3.0 / 7.0); c.a62 = h * (2.0 / 7.0); c.a63 = h * (12.0 / 7.0); c.a65 = h * (8.0 / 7.0);
-    c.b1 = h * (7.0 / 90.0); c.b3 = h * (32.0 / 90.0); c.b4 = h * (12.0 / 90.0);
-    double t = 0.0;
-#pragma unroll 1
-    for (int s = 0; s < n; ++s) {
-        double k1[NV], y[NV], p4[NV], p5[NV], p6[NV], pb[NV];
-        if (s > 0) stage(a, t);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { k1[i] = k[i]; y[i] = __builtin_fma(c.a21, k[i], a[i]); }
-        stage(y, __builtin_fma(0.25, h, t));
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            y[i] = __builtin_fma(c.a31, k[i], __builtin_fma(c.a31, k1[i], a[i]));
-            p4[i] = __builtin_fma(c.a42, k[i], a[i]);
-            p6[i] = __builtin_fma(c.a62, k[i], __builtin_fma(c.a61, k1[i], a[i]));
-        }
-        stage(y, __builtin_fma(0.25, h, t));
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            y[i] = __builtin_fma(h, k[i], p4[i]); p6[i] = __builtin_fma(c.a63, k[i], p6[i]);
-            pb[i] = __builtin_fma(c.b3, k[i], __builtin_fma(c.b1, k1[i], a[i]));
-            p5[i] = __builtin_fma(c.a51, k1[i], a[i]);
-        }
-        stage(y, __builtin_fma(0.5, h, t));
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            y[i] = __builtin_fma(c.a54, k[i], p5[i]); p6[i] = __builtin_fma(-c.a63, k[i], p6[i]); pb[i] = __builtin_fma(c.b4, k[i], pb[i]);
-        }
-        stage(y, __builtin_fma(0.75, h, t));
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { y[i] = __builtin_fma(c.a65, k[i], p6[i]); pb[i] = __builtin_fma(c.b3, k[i], pb[i]); }
-        t = t + h;
-        stage(y, t);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) a[i] = __builtin_fma(c.b1, k[i], pb[i]);
-    }
-    a[A_SO] = slaved ? a[A_SO] * sbr_rcp(__builtin_fma(lam0, span, 1.0)) : a[A_SO];
-    const double c14 = 1.0 / 14.0;
-    const double v1 = __builtin_fma(Q, span, v0);
-    const double g = (Q * span) * sbr_rcp(v1);                  // share of the final volume that flowed in
-    const double u_in = __builtin_fma(-(ld[10] - ld[9]), c14, ld[13]);
-    double u = __builtin_fma(-n0, c14, x[13]);
-    u = __builtin_fma(g, u_in - u, u);
-    {
-        double a9[SBR_NA];
-#pragma unroll
-        for (int i = 0; i < SBR_NA; ++i) a9[i] = a[i];
-        sbr_scatter(a9, x);
-    }
-    x[7] = a[SBR_NA];
-    x[0] = v1;
-    x[1] = __builtin_fma(g, ld[1] - x[1], x[1]);
-    x[3] = __builtin_fma(g, ld[3] - x[3], x[3]);
     x[13] = __builtin_fma(x[10] - x[9], c14, u);
 }
 // m macro intervals of span/m each, closed reactor (the idle phase of the done call: m = ceil(rows / 10))
@@ -1141,12 +1029,10 @@ SBR_DEV double sbr_cycle_phase(const SbrPar& p, double (&x)[SBR_NX], int ph, dou
         if (k > p.Kla_max) { k = p.Kla_max; ie = ie - e * p.cyc_dt; }
         if (k < p.Kla_min) { k = p.Kla_min; ie = ie - e * p.cyc_dt; }
         if (i == 0) bias = k;
-        if constexpr (SCH == 1) {                                  // scheme 1: every interval by the adaptive steps
-            if constexpr (FILL) sbr_b5a_fill(p, x, g1 - g0, k, ld);
-            else sbr_b5a<false>(p, x, g1 - g0, k, 0.0);
-        } else {
-            sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
-        }
+        // scheme 1: every interval but the fill phase's (a fill interval is not plannable from its start state: the inflow raises
+        // Ss and Snh severalfold WITHIN the interval and the oxygen uptake with them - measured: up to 70 gates, profiles/r05_notes.md)
+        if constexpr (SCH == 1 && !FILL) sbr_b5a<false>(p, x, g1 - g0, k, 0.0);
+        else sbr_rk4<FILL ? 2 : 0>(p, x, (g1 - g0) * p.inv_substeps, p.substeps, k, FILL ? ld[0] : 0.0, ld);
         sum = sum + k;
         so_prev = so; so = x[8];
     }

@@ -116,17 +116,18 @@ typedef struct sbr_config {
                                   per env and reset on the device, uniformly, as SbrEnv4.reset does with
                                   np.random.choice(8, 1) (gym_SBR_env4.py:107): Philox4x32-10 keyed by `seed`, stream 2,
                                   subsequence = GLOBAL env id (sbr_draw_scenarios returns the same draw) */
-    int32_t scheme;            /* how every span with Kla and the flows held is integrated - the control intervals of sbr_step /
-                                  sbr_rollout (reaction_dxdt :1658-1787, odeint call sites :1953, :2041), the fill phase of sbr_reset
-                                  (:1647), the idle phase of the done call (:2587) and the intervals of sbr_cycle_step.
+    int32_t scheme;            /* how the control intervals of sbr_step / sbr_rollout (reaction_dxdt :1658-1787, odeint call sites
+                                  :1953, :2041), the idle phase of the done call (:2587) and the reaction and idle intervals of
+                                  sbr_cycle_step are integrated.  (The fill phase - sbr_reset, :1647, and sbr_cycle_step's first
+                                  phase - is integrated with RK4, h = dt, under either scheme.)
                                   0: classical RK4, `substeps` substeps per control interval (40 right-hand-side evaluations).
                                   1 (default, round 5): Butcher's fifth-order scheme with 1, 2 or 4 steps chosen per env and
                                   interval from the env's own state - dissolved oxygen, the system's one stiff mode, is held
                                   where it is slaved to zero, and an env whose oxygen mode is stiffer than the reference plant's
                                   takes more steps: ~10 evaluations per interval, and closer to the
                                   reference's trajectories than scheme 0 (closed loop, worst 0.41 of the 1e-5 gate against 0.51).
-                                  `substeps` is then unused; the fill and idle phases are cut into ceil(rows / 10) macro
-                                  intervals.  sbr_eval_substeps replays RK4 nodes under either scheme. */
+                                  `substeps` then only sets the fill intervals of sbr_cycle_step; the idle phase is cut into
+                                  ceil(rows / 10) macro intervals.  sbr_eval_substeps replays RK4 nodes under either scheme. */
     int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; must be 0 */
 } sbr_config;
 

@@ -235,31 +235,30 @@ static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, 
  * A span with Kla and the flows held, by Butcher's six-stage fifth-order scheme with a step count chosen from the plant's own
  * state at the start of every macro interval (a control interval; the idle phase is cut into ceil(rows/10) of them).  Same
  * operations in the same order as oracle/sbr_ref.py b5a_plan / b5_step / b5a_span (bit-identical); the reasoning is written
- * there and in DESIGN.md 4.3.   kind 0: reaction (ec != 0: scaled-mass form)   1: fill (loading)   2: idle */
+ * there and in DESIGN.md 3.0.   kind 0: reaction (ec != 0: scaled-mass form)   2: idle / closed reactor.  The fill phase is never
+ * integrated this way (not plannable from its start state: the inflow changes Ss and Snh severalfold within an interval). */
 #define B5A_SO_SLAVED 1e-9
 #define B5A_Z1 0.3
 #define B5A_Z2 1.0
 #define B5A_Z_STAB 3.0
 #define B5A_N_MAX 64
 
-static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, double kla, double ec, const double* loading,
-                    int hold_so, double* k) {
-    if (kind == 1) sbro_rhs_fill(p, y, kla, loading, k);
-    else if (kind == 2) sbro_rhs_idle(p, y, kla, k);
+static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, double kla, double ec, int hold_so, double* k) {
+    if (kind == 2) sbro_rhs_idle(p, y, kla, k);
     else if (ec != 0.0) rhs_reaction_w(p, y, v0, kla, ec, k);
     else sbro_rhs_reaction(p, y, kla, ec, k);
     if (hold_so) k[8] = 0.0;
 }
 
 /* one macro interval; returns the step count */
-static int b5a_macro(const sbro_params* p, int kind, double* x, double span, double kla, double ec, const double* loading) {
+static int b5a_macro(const sbro_params* p, int kind, double* x, double span, double kla, double ec) {
     static const double A21 = 0.25, A31 = 0.125, A32 = 0.125, A42 = -0.5, A43 = 1.0, A51 = 3.0 / 16.0, A54 = 9.0 / 16.0,
                         A61 = -3.0 / 7.0, A62 = 2.0 / 7.0, A63 = 12.0 / 7.0, A64 = -12.0 / 7.0, A65 = 8.0 / 7.0,
                         B1 = 7.0 / 90.0, B3 = 32.0 / 90.0, B4 = 12.0 / 90.0, B5 = 32.0 / 90.0, B6 = 7.0 / 90.0;
     const double v0 = x[0];
     const int dose = (kind == 0 && ec != 0.0);
     double k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX];
-    b5a_rhs(p, kind, x, v0, kla, ec, loading, 0, k1);
+    b5a_rhs(p, kind, x, v0, kla, ec, 0, k1);
     /* the plan */
     const double ss = x[2], xbh = x[5], xba = x[6], so = x[8], snh = x[10];
     const double a1 = ((1 - p->Yh) / p->Yh) * p->muH * (ss / (p->Ks + ss)) * xbh;
@@ -283,18 +282,18 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
     const double h = span / n;
     if (slaved) k1[8] = 0.0;
     for (int s = 0; s < n; ++s) {
-        if (s > 0) b5a_rhs(p, kind, x, v0, kla, ec, loading, slaved, k1);
+        if (s > 0) b5a_rhs(p, kind, x, v0, kla, ec, slaved, k1);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A21) * k1[i];
-        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k2);
+        b5a_rhs(p, kind, y, v0, kla, ec, slaved, k2);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A31) * k1[i] + (h * A32) * k2[i];
-        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k3);
+        b5a_rhs(p, kind, y, v0, kla, ec, slaved, k3);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A42) * k2[i] + (h * A43) * k3[i];
-        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k4);
+        b5a_rhs(p, kind, y, v0, kla, ec, slaved, k4);
         for (int i = 0; i < NX; ++i) y[i] = x[i] + (h * A51) * k1[i] + (h * A54) * k4[i];
-        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k5);
+        b5a_rhs(p, kind, y, v0, kla, ec, slaved, k5);
         for (int i = 0; i < NX; ++i)
             y[i] = x[i] + (h * A61) * k1[i] + (h * A62) * k2[i] + (h * A63) * k3[i] + (h * A64) * k4[i] + (h * A65) * k5[i];
-        b5a_rhs(p, kind, y, v0, kla, ec, loading, slaved, k6);
+        b5a_rhs(p, kind, y, v0, kla, ec, slaved, k6);
         for (int i = 0; i < NX; ++i)
             x[i] = x[i] + (h * B1) * k1[i] + (h * B3) * k3[i] + (h * B4) * k4[i] + (h * B5) * k5[i] + (h * B6) * k6[i];
     }
@@ -307,16 +306,16 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
 }
 
 /* m macro intervals of span/m each; returns the step count of the last one */
-static int b5a_span(const sbro_params* p, int kind, double* x, double span, int m, double kla, double ec, const double* loading) {
+static int b5a_span(const sbro_params* p, int kind, double* x, double span, int m, double kla, double ec) {
     const double hm = span / m;
     int n = 0;
-    for (int j = 0; j < m; ++j) n = b5a_macro(p, kind, x, hm, kla, ec, loading);
+    for (int j = 0; j < m; ++j) n = b5a_macro(p, kind, x, hm, kla, ec);
     return n;
 }
 
 /* scheme-aware integration of one reaction interval (python: SbrOsRef._integrate); returns the step count (-1: scheme 0) */
 int sbro_reaction_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
-    if (p->scheme == 1) return b5a_span(p, 0, x, span, 1, kla, ec, 0);
+    if (p->scheme == 1) return b5a_span(p, 0, x, span, 1, kla, ec);
     rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
     return -1;
 }
@@ -324,7 +323,7 @@ int sbro_reaction_interval(const sbro_params* p, double* x, double span, double 
 /* the idle phase (kind 2) under the handle's scheme: scheme 1 cuts its `rows` RK4-substep-long span into ceil(rows/10) macro
  * intervals of the adaptive scheme */
 static void idle_span(const sbro_params* p, double* x, double span, int rows, double kla) {
-    if (p->scheme == 1) b5a_span(p, 2, x, span, (rows + 9) / 10, kla, 0, 0);
+    if (p->scheme == 1) b5a_span(p, 2, x, span, (rows + 9) / 10, kla, 0);
     else rk4_span(p, 2, x, span, rows, kla, 0, 0);
 }
 
@@ -447,8 +446,7 @@ static void reset_from(const sbro_params* p, sbro_env* e, const double* influent
     const int n_rows = (int)((t_end - 0) / p->dt);      /* 252 */
     double x0c[NX];
     memcpy(x0c, e->x, sizeof x0c);
-    if (p->scheme == 1) b5a_span(p, 1, e->x, t_end, (n_rows + 9) / 10, kla, 0, e->influent);     /* ceil(rows / 10) macro intervals */
-    else rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);
+    rk4_span(p, 1, e->x, t_end, n_rows, kla, 0, e->influent);      /* the fill phase: RK4 under either scheme (not plannable) */
     e->so_m2 = x0v[8]; e->so_m1 = e->x[8];
     e->sno_m2 = x0v[9]; e->sno_m1 = e->x[2];          /* :1652 stores Ss in the Sno memory */
     e->t = t_end;
@@ -757,7 +755,7 @@ static double cycle_phase(const sbro_params* p, double* x, double t_start, doubl
         if (k > p->Kla_max) { k = p->Kla_max; ie = ie - e * p->cyc_dt; }
         if (k < p->Kla_min) { k = p->Kla_min; ie = ie - e * p->cyc_dt; }
         if (i == 0) bias = k;
-        if (p->scheme == 1) b5a_span(p, loading ? 1 : 2, x, g1 - g0, 1, k, 0, loading);      /* scheme 1: every interval */
+        if (p->scheme == 1 && !loading) b5a_span(p, 2, x, g1 - g0, 1, k, 0);     /* scheme 1: every interval but the fill phase's */
         else rk4_span(p, loading ? 1 : 2, x, g1 - g0, p->substeps, k, 0, loading);
         sum = sum + k;
         if (kla_log) kla_log[i] = k;

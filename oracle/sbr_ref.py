@@ -186,9 +186,10 @@ def rk4_reaction_w(x, t0, t1, n, kla, ec):
 #     reaches (consumption slows as So falls, so the projection bounds So from below and z from above);
 #   * in the last case - the knee, where So moves through K_OH - n = max(4, floor(lam(0) span / 3.0) + 1): the worst-case
 #     lam(0) h stays below 3.0 (Butcher-5 is stable on the real axis up to 3.39; the reference plant never needs more than 4);
-#   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) and the fill phase of reset() (:1585-1654, one
-#     odeint over 252 dt, right-hand side filling_dxdt) are cut into ceil(rows/10) macro intervals, each planned like a control
-#     interval.
+#   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) is cut into ceil(rows/10) macro intervals, each
+#     planned like a control interval.  The FILL phase (:1585-1654) stays with RK4 under either scheme: a fill interval cannot be
+#     planned from its start state - the inflow raises Ss and Snh severalfold within the interval, and the oxygen uptake with
+#     them (planned on its own, a fill interval of SBR-v2 was up to 70 gates off: scripts/analysis/cycle_intervals.py).
 # oracle/sbr_oracle.c b5a_interval does the same operations in the same order (bit-identical, tests/test_oracle_golden.py).
 B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB, B5A_N_MAX = 1e-9, 0.3, 1.0, 3.0, 64
 _A21, _A31, _A32, _A42, _A43, _A51, _A54 = 0.25, 0.125, 0.125, -0.5, 1.0, 3.0 / 16.0, 9.0 / 16.0
@@ -239,15 +240,12 @@ def b5_step(f, x, h, k1, hold_so):
     return x + (h * _B1) * k1 + (h * _B3) * k3 + (h * _B4) * k4 + (h * _B5) * k5 + (h * _B6) * k6
 
 
-def b5a_macro(kind, x, span, kla, ec=0.0, loading=None):
-    """One macro interval of scheme 1.  kind 0: reaction (ec != 0: scaled-mass form), 1: fill (loading), 2: idle.
-    Returns (x_end, n)."""
+def b5a_macro(kind, x, span, kla, ec=0.0):
+    """One macro interval of scheme 1.  kind 0: reaction (ec != 0: scaled-mass form), 2: idle.  Returns (x_end, n)."""
     x = np.array(x, dtype=np.float64)
     v0 = x[0]
     dose = kind == 0 and ec != 0
-    if kind == 1:
-        f = lambda y: rhs_fill(y, 0.0, kla, loading)        # noqa: E731
-    elif kind == 2:
+    if kind == 2:
         f = lambda y: rhs_idle(y, 0.0, kla)                 # noqa: E731
     elif dose:
         f = lambda y: rhs_reaction_w(y, v0, kla, ec)        # noqa: E731   scaled-mass variables, as rk4_reaction_w
@@ -272,13 +270,13 @@ def b5a_macro(kind, x, span, kla, ec=0.0, loading=None):
     return x, n
 
 
-def b5a_span(kind, x, span, m, kla, ec=0.0, loading=None):
+def b5a_span(kind, x, span, m, kla, ec=0.0):
     """m macro intervals of span/m each (a control interval: m = 1; the idle phase: ceil(rows/10)).  Returns (x_end, n of
     the last macro interval)."""
     hm = span / m
     n = 0
     for _ in range(m):
-        x, n = b5a_macro(kind, x, hm, kla, ec, loading)
+        x, n = b5a_macro(kind, x, hm, kla, ec)
     return x, n
 
 
@@ -333,8 +331,6 @@ class SbrOsRef:
             return x1, None
         if f is rhs_idle and self.scheme == 1:
             return b5a_span(2, x, t1 - t0, (n_sub + 9) // 10, args[0])[0], None
-        if f is rhs_fill and self.scheme == 1:
-            return b5a_span(1, x, t1 - t0, (n_sub + 9) // 10, args[0], 0.0, args[1])[0], None
         if f is rhs_reaction and args[1] != 0:          # a dosing interval: RK4 on the scaled-mass system (rk4_reaction_w)
             return rk4_reaction_w(x, t0, t1, n_sub, *args), None
         return rk4(f, x, t0, t1, n_sub, args), None
