@@ -428,8 +428,11 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 //     m_so = 0) and damped afterwards by 1/(1 + lam(0) span);
 //   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span < 0.3 / < 1.0 / else, So_lo = max(0, min(So, So + So' span)): the
 //     lowest So a linear projection reaches (consumption slows as So falls, so it bounds So from below and z from above);
-//   * in the last case (the knee, So moving through Koh) n = max(4, floor(lam(0) span / 3) + 1): the worst-case lam(0) h stays
-//     below 3.0 (Butcher-5 is stable on the real axis up to 3.39); the reference plant never needs more than four steps.
+//   * in the last case (the knee, So moving through Koh) n = max(4, floor(lam(0) span / 2.5) + 1): the worst-case lam(0) h stays
+//     below 2.5 (Butcher-5 is stable on the real axis up to 3.39); the reference plant needs four steps (five in one golden episode);
+//   * a1 and a3 are taken at the projected upper ends of Ss and Snh over the interval, and the count is never below what the
+//     movement of the other Monod arguments asks for (zs = max |slope| span / (K + |x|) over Ss, Snh, Sno: < 0.15 -> 1, < 0.5 -> 2,
+//     else 4): no effect on the reference's regime, robustness for plants driven far from it (scripts/analysis/plan_probe.py).
 // The step count is a function of the lane's own state only, and lanes that take fewer steps than their wave-mates are masked
 // out of the later iterations: an env's bits do not depend on which envs share its wavefront (as with the dosing ballot).
 // The steps are written in running-sum form - each stage slope is added to the pending stage bases and the result as soon as
@@ -452,25 +455,46 @@ SBR_DEV void sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double k
     sbr_rates(p, m, a, kla, k, o);
     if (DOSE) k[A_SS] = k[A_SS] + srcr;
     k[A_SNO] = k[A_SNO] * p.n9_3;
-    // ---- the plan (oracle: b5a_plan)
-    const double so = a[A_SO];
-    const double proj = __builtin_fma(k[A_SO], span, so);
+    // ---- the plan (oracle: b5a_plan).  Everything the oxygen rate is built from is taken at its upper bound over the interval
+    // under a linear projection of the slow variables: Ss and Snh at max(start, start + slope span) (carbon dosing raises Ss
+    // within an interval), So at the lowest value the steeper of (its start slope, its slope with the projected substrate levels)
+    // reaches.  One reciprocal for the four Monod quotients at the start and projected levels, one for the two oxygen terms.
+    const double so = a[A_SO], ss = a[A_SS], snh = a[A_SNH];
+    const double p2 = __builtin_fma(k[A_SS], span, ss), p10 = __builtin_fma(k[A_SNH], span, snh);
+    const double ss_hi = p2 > ss ? p2 : ss, snh_hi = p10 > snh ? p10 : snh;
+    const double e1 = p.Ks + ss, e2 = p.Ks + ss_hi, e3 = p.Knh + snh, e4 = p.Knh + snh_hi;
+    const double e12 = e1 * e2, e34 = e3 * e4;
+    const double Rm = sbr_rcp(e12 * e34);
+    const double r12 = Rm * e34, r34 = Rm * e12;                 // 1/((Ks+Ss)(Ks+Ss_hi)), 1/((Knh+Snh)(Knh+Snh_hi))
+    const double m1s = ss * (r12 * e2), m1 = ss_hi * (r12 * e1), m3s = snh * (r34 * e4), m3 = snh_hi * (r34 * e3);
+    const double c1 = (-p.n8_1 * p.muH) * a[A_XBH], c3 = (-p.n8_3 * p.muA) * a[A_XBA];
+    const double a1 = c1 * m1, a3 = c3 * m3;
+    const double g1 = p.Koh + so, g3 = p.Koa + so;
+    const double Rg = sbr_rcp(g1 * g3);
+    const double slope_hi = __builtin_fma(-(c1 * (m1 - m1s)), so * (Rg * g3), __builtin_fma(-(c3 * (m3 - m3s)), so * (Rg * g1), k[A_SO]));
+    const double slope = slope_hi < k[A_SO] ? slope_hi : k[A_SO];
+    const double proj = __builtin_fma(slope, span, so);
     const double lo1 = proj < so ? proj : so;
     const double so_lo = lo1 > 0.0 ? lo1 : 0.0;
     const double dh = p.Koh + so_lo, da = p.Koa + so_lo;
-    const double P1 = (p.Ks + a[A_SS]) * (dh * dh), P3 = (p.Knh + a[A_SNH]) * (da * da);
-    const double R = sbr_rcp(P1 * P3);
-    const double r1 = R * P3, r3 = R * P1;                       // 1/((Ks+Ss)(Koh+So_lo)^2), 1/((Knh+Snh)(Koa+So_lo)^2)
-    const double c1 = (-p.n8_1 * p.muH) * (a[A_SS] * a[A_XBH]), c3 = (-p.n8_3 * p.muA) * (a[A_SNH] * a[A_XBA]);
-    const double z_ub = __builtin_fma(c1 * p.Koh, r1, __builtin_fma(c3 * p.Koa, r3, kla)) * span;
-    const double lam0 = __builtin_fma(c1 * p.inv_Koh, r1 * (dh * dh), __builtin_fma(c3 * p.inv_Koa, r3 * (da * da), kla));
+    const double dh2 = dh * dh, da2 = da * da;
+    const double R = sbr_rcp(dh2 * da2);
+    const double z_ub = __builtin_fma(a1 * p.Koh, R * da2, __builtin_fma(a3 * p.Koa, R * dh2, kla)) * span;
+    const double lam0 = __builtin_fma(a1, p.inv_Koh, __builtin_fma(a3, p.inv_Koa, kla));
     const bool slaved = (fabs(so) < 1e-9) && (kla_sat * span < 1e-9);
-    // n = 2 (slaved) / 1 / 2 / the knee: max(4, floor(lam(0) span / 3) + 1), capped at 64 so that every wave terminates
-    const double qn = lam0 * span * (1.0 / 3.0);
+    // n = 2 (slaved) / 1 / 2 / the knee: max(4, floor(lam(0) span / 2.5) + 1), capped at 64 so that every wave terminates
+    const double qn = lam0 * span * (1.0 / 2.5);
     const int n_knee = qn < 4.0 ? 4 : (!(qn < 64.0) ? 64 : (int)qn + 1);
-    const int n = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : n_knee));
+    const int n_z = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : n_knee));
+    // ... and never fewer steps than the other Monod arguments ask for: |slope| span / (K + |x|) of Ss, Snh, Sno
+    const double f2 = p.Ks + fabs(ss), f10 = p.Knh + fabs(snh), f9 = p.Kno + fabs(a[A_SNO]);
+    const double Rs = sbr_rcp((f2 * f10) * f9);
+    const double zs2 = fabs(k[A_SS]) * (Rs * (f10 * f9)), zs10 = fabs(k[A_SNH]) * (Rs * (f2 * f9)), zs9 = fabs(k[A_SNO]) * (Rs * (f2 * f10));
+    const double zsm = (zs2 > zs10 ? (zs2 > zs9 ? zs2 : zs9) : (zs10 > zs9 ? zs10 : zs9)) * span;
+    const int n_s = zsm < 0.15 ? 1 : (zsm < 0.5 ? 2 : 4);
+    const int n = n_s > n_z ? n_s : n_z;
     const double m_so = slaved ? 0.0 : 1.0;
-    // span / n: exact for 1, 2 and 4 (every step count of the reference plant); one reciprocal for the rest
+    // span / n: exact for 1, 2 and 4 (nearly every step count of the reference plant); one reciprocal for the rest
     const double h = n == 1 ? span : (n == 2 ? span * 0.5 : (n == 4 ? span * 0.25 : span * sbr_rcp((double)n)));
     k[A_SO] = k[A_SO] * m_so;
     SbrB5C c;

@@ -240,7 +240,9 @@ static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, 
 #define B5A_SO_SLAVED 1e-9
 #define B5A_Z1 0.3
 #define B5A_Z2 1.0
-#define B5A_Z_STAB 3.0
+#define B5A_Z_STAB 2.5
+#define B5A_ZS1 0.15
+#define B5A_ZS2 0.5
 #define B5A_N_MAX 64
 
 static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, double kla, double ec, int hold_so, double* k) {
@@ -259,13 +261,22 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
     const int dose = (kind == 0 && ec != 0.0);
     double k1[NX], k2[NX], k3[NX], k4[NX], k5[NX], k6[NX], y[NX];
     b5a_rhs(p, kind, x, v0, kla, ec, 0, k1);
-    /* the plan */
-    const double ss = x[2], xbh = x[5], xba = x[6], so = x[8], snh = x[10];
-    const double a1 = ((1 - p->Yh) / p->Yh) * p->muH * (ss / (p->Ks + ss)) * xbh;
-    const double a3 = ((4.57 - p->Ya) / p->Ya) * p->muA * (snh / (p->Knh + snh)) * xba;
+    /* the plan (python: b5a_plan) */
+    const double ss = x[2], xbh = x[5], xba = x[6], so = x[8], sno = x[9], snh = x[10];
+    const double p2 = ss + k1[2] * span;
+    const double ss_hi = p2 > ss ? p2 : ss;
+    const double p10 = snh + k1[10] * span;
+    const double snh_hi = p10 > snh ? p10 : snh;
+    const double c1 = ((1 - p->Yh) / p->Yh) * p->muH * xbh;
+    const double c3 = ((4.57 - p->Ya) / p->Ya) * p->muA * xba;
+    const double m1s = ss / (p->Ks + ss), m3s = snh / (p->Knh + snh);
+    const double m1 = ss_hi / (p->Ks + ss_hi), m3 = snh_hi / (p->Knh + snh_hi);
+    const double a1 = c1 * m1, a3 = c3 * m3;
 #define LAM(s_) (a1 * p->Koh / ((p->Koh + (s_)) * (p->Koh + (s_))) + a3 * p->Koa / ((p->Koa + (s_)) * (p->Koa + (s_))) + kla)
     const int slaved = (fabs(so) < B5A_SO_SLAVED) && (kla * p->So_sat * span < B5A_SO_SLAVED);
-    const double proj = so + k1[8] * span;
+    const double slope_hi = k1[8] - c1 * (m1 - m1s) * (so / (p->Koh + so)) - c3 * (m3 - m3s) * (so / (p->Koa + so));
+    const double slope = slope_hi < k1[8] ? slope_hi : k1[8];
+    const double proj = so + slope * span;
     const double lo1 = proj < so ? proj : so;
     const double so_lo = lo1 > 0.0 ? lo1 : 0.0;
     const double z_ub = LAM(so_lo) * span;
@@ -278,6 +289,15 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
     else {                                  /* the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39) */
         const double q = lam0 * span / B5A_Z_STAB;
         n = q < 4.0 ? 4 : (!(q < (double)B5A_N_MAX) ? B5A_N_MAX : (int)q + 1);
+    }
+    {   /* how far the arguments of the other Monod terms move within the interval */
+        double zs = fabs(k1[2]) * span / (p->Ks + fabs(ss));
+        const double z10 = fabs(k1[10]) * span / (p->Knh + fabs(snh));
+        const double z9 = fabs(k1[9]) * span / (p->Kno + fabs(sno));
+        zs = z10 > zs ? z10 : zs;
+        zs = z9 > zs ? z9 : zs;
+        const int n_s = zs < B5A_ZS1 ? 1 : (zs < B5A_ZS2 ? 2 : 4);
+        n = n_s > n ? n_s : n;
     }
     const double h = span / n;
     if (slaved) k1[8] = 0.0;

@@ -183,31 +183,48 @@ def rk4_reaction_w(x, t0, t1, n, kla, ec):
 #     afterwards by 1/(1 + lam(0) span): TWO steps (one step's local error, <= 0.035 of the gate, is amplified past the
 #     gate by the NO3-PID -> dosing loop in the golden episode random_b; two steps: 0.0008);
 #   * otherwise n = 1, 2 or 4 steps from z = lam(So_lo) span, So_lo = the lowest So a linear projection over the interval
-#     reaches (consumption slows as So falls, so the projection bounds So from below and z from above);
-#   * in the last case - the knee, where So moves through K_OH - n = max(4, floor(lam(0) span / 3.0) + 1): the worst-case
-#     lam(0) h stays below 3.0 (Butcher-5 is stable on the real axis up to 3.39; the reference plant never needs more than 4);
+#     reaches (consumption slows as So falls, so the projection bounds So from below and z from above), with a1 and a3 taken at
+#     the projected upper ends of Ss and Snh (carbon dosing raises Ss by up to 3 g/m3 within an interval);
+#   * in the last case - the knee, where So moves through K_OH - n = max(4, floor(lam(0) span / 2.5) + 1): the worst-case
+#     lam(0) h stays below 2.5 (Butcher-5 is stable on the real axis up to 3.39; the reference plant needs 4, 5 in `zeros`);
+#   * and never fewer steps than the OTHER Monod arguments ask for: zs = max |slope_i| span / (K_i + |x_i|) over Ss, Snh, Sno
+#     below 0.15 -> 1, below 0.5 -> 2, else 4 (no effect on any reference-captured interval; it matters for plants driven far
+#     from the reference's regime, scripts/analysis/plan_probe.py);
 #   * the idle phase of the done call (:2554-2597, one odeint over ~464 dt) is cut into ceil(rows/10) macro intervals, each
 #     planned like a control interval.  The FILL phase (:1585-1654) stays with RK4 under either scheme: a fill interval cannot be
 #     planned from its start state - the inflow raises Ss and Snh severalfold within the interval, and the oxygen uptake with
 #     them (planned on its own, a fill interval of SBR-v2 was up to 70 gates off: scripts/analysis/cycle_intervals.py).
 # oracle/sbr_oracle.c b5a_interval does the same operations in the same order (bit-identical, tests/test_oracle_golden.py).
-B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB, B5A_N_MAX = 1e-9, 0.3, 1.0, 3.0, 64
+B5A_SO_SLAVED, B5A_Z1, B5A_Z2, B5A_Z_STAB, B5A_N_MAX = 1e-9, 0.3, 1.0, 2.5, 64
+B5A_ZS1, B5A_ZS2 = 0.15, 0.5
 _A21, _A31, _A32, _A42, _A43, _A51, _A54 = 0.25, 0.125, 0.125, -0.5, 1.0, 3.0 / 16.0, 9.0 / 16.0
 _A61, _A62, _A63, _A64, _A65 = -3.0 / 7.0, 2.0 / 7.0, 12.0 / 7.0, -12.0 / 7.0, 8.0 / 7.0
 _B1, _B3, _B4, _B5, _B6 = 7.0 / 90.0, 32.0 / 90.0, 12.0 / 90.0, 32.0 / 90.0, 7.0 / 90.0
 
 
-def b5a_plan(x, k1_so, span, kla):
-    """(n, slaved, lam0): the step count of one macro interval from its start state, the slope of So there (first stage of
-    the first step, which does not depend on the step size), the span and Kla."""
-    ss, xbh, xba, so, snh = x[2], x[5], x[6], x[8], x[10]
-    a1 = ((1 - P.YH) / P.YH) * P.MUH * (ss / (P.KS + ss)) * xbh
-    a3 = ((4.57 - P.YA) / P.YA) * P.MUA * (snh / (P.KNH + snh)) * xba
+def b5a_plan(x, k1, span, kla):
+    """(n, slaved, lam0): the step count of one macro interval from its start state x, the first stage slope k1 = f(x) (which
+    does not depend on the step size), the span and Kla.  Everything the oxygen rate is built from is taken at its UPPER bound
+    over the interval under a linear projection of the slow variables: Ss and Snh at max(start, start + slope span) (carbon
+    dosing raises Ss within an interval), So at the lowest value the steeper of (its start slope, its slope with the projected
+    substrate levels) reaches."""
+    ss, xbh, xba, so, sno, snh = x[2], x[5], x[6], x[8], x[9], x[10]
+    p2 = ss + k1[2] * span
+    ss_hi = p2 if p2 > ss else ss
+    p10 = snh + k1[10] * span
+    snh_hi = p10 if p10 > snh else snh
+    c1 = ((1 - P.YH) / P.YH) * P.MUH * xbh
+    c3 = ((4.57 - P.YA) / P.YA) * P.MUA * xba
+    m1s, m3s = ss / (P.KS + ss), snh / (P.KNH + snh)
+    m1, m3 = ss_hi / (P.KS + ss_hi), snh_hi / (P.KNH + snh_hi)
+    a1, a3 = c1 * m1, c3 * m3
 
     def lam(s):
         return a1 * P.KOH / ((P.KOH + s) * (P.KOH + s)) + a3 * P.KOA / ((P.KOA + s) * (P.KOA + s)) + kla
     slaved = (abs(so) < B5A_SO_SLAVED) and (kla * P.SO_SAT * span < B5A_SO_SLAVED)
-    proj = so + k1_so * span
+    slope_hi = k1[8] - c1 * (m1 - m1s) * (so / (P.KOH + so)) - c3 * (m3 - m3s) * (so / (P.KOA + so))
+    slope = slope_hi if slope_hi < k1[8] else k1[8]
+    proj = so + slope * span
     lo1 = proj if proj < so else so
     so_lo = lo1 if lo1 > 0.0 else 0.0
     z_ub = lam(so_lo) * span
@@ -221,7 +238,14 @@ def b5a_plan(x, k1_so, span, kla):
     else:                                   # the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39)
         q = lam0 * span / B5A_Z_STAB
         n = 4 if q < 4.0 else (B5A_N_MAX if not (q < float(B5A_N_MAX)) else int(q) + 1)
-    return n, slaved, lam0
+    # how far the arguments of the other Monod terms move within the interval: |slope| span / (K + |x|)
+    zs = abs(k1[2]) * span / (P.KS + abs(ss))
+    z10 = abs(k1[10]) * span / (P.KNH + abs(snh))
+    z9 = abs(k1[9]) * span / (P.KNO + abs(sno))
+    zs = z10 if z10 > zs else zs
+    zs = z9 if z9 > zs else zs
+    n_s = 1 if zs < B5A_ZS1 else (2 if zs < B5A_ZS2 else 4)
+    return (n_s if n_s > n else n), slaved, lam0
 
 
 def b5_step(f, x, h, k1, hold_so):
@@ -252,7 +276,7 @@ def b5a_macro(kind, x, span, kla, ec=0.0):
     else:
         f = lambda y: rhs_reaction(y, 0.0, kla, ec)         # noqa: E731
     k1 = f(x)
-    n, slaved, lam0 = b5a_plan(x, k1[8], span, kla)
+    n, slaved, lam0 = b5a_plan(x, k1, span, kla)
     h = span / n
     if slaved:
         k1[8] = 0.0

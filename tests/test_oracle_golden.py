@@ -490,7 +490,7 @@ def test_scheme1_layer2_c_is_bit_identical_to_layer1(name, tables):
         if k < n - 1:
             assert np.array_equal(b.envs["x"][0], py.x)                # ... and the same bits
     assert np.array_equal(b.envs["x"][0], py.x_after_idle) and b.envs["qw"][0] == py.qw
-    assert set(py.step_counts) <= {1, 2, 4}
+    assert set(py.step_counts) <= {1, 2, 4, 5}                        # 5: the knee of `zeros` (lam(0) span / 2.5 just above 4)
 
 
 def test_scheme1_open_loop_every_interval_inside_gate():
@@ -510,7 +510,7 @@ def test_scheme1_open_loop_every_interval_inside_gate():
             hist[n] = hist.get(n, 0) + 1
             evals += 6 * n
             count += 1
-    assert count == 9661 and set(hist) == {1, 2, 4}                     # the reference plant never needs more than four steps
+    assert count == 9661 and set(hist) <= {1, 2, 4, 5} and hist.get(5, 0) < 300   # 5: only where lam(0) span / 2.5 >= 4 (`zeros`)
     assert worst <= 0.3, worst                                          # measured 0.2251 (So, aeration switch-on, scn3_c25)
     assert evals / count < 11.0, evals / count                          # measured 10.2 (slaved intervals take two steps)
 
@@ -536,12 +536,12 @@ def test_scheme1_closed_loop_inside_gate_of_the_reference_at_tight_tolerance(nam
         assert gate(xs[n - 1], e["term_x_after_idle"]).max() <= 1.0
         assert abs(b.envs["ret"][0] / float(e["episode_return"]) - 1) < 1e-5
         assert abs(b.envs["qw"][0] / float(e["term_Qw"]) - 1) < 1e-5
-        assert set(steps) <= {1, 2, 4}                                  # the reference plant never needs more than four
+        assert set(steps) <= {1, 2, 4, 5}                               # the reference plant never needs more than five
 
 
 def test_scheme1_takes_more_steps_where_four_would_be_unstable():
-    """The stability rule of the knee: n = max(4, floor(lam(0) span / 3) + 1), so that the worst-case oxygen rate times the
-    step stays below 3.0 (Butcher-5 is stable on the real axis up to 3.39).  The reference plant never needs more than four
+    """The stability rule of the knee: n = max(4, floor(lam(0) span / 2.5) + 1), so that the worst-case oxygen rate times the
+    step stays below 2.5 (Butcher-5 is stable on the real axis up to 3.39).  The reference plant never needs more than four
     (lam(0) span / 4 <= 2.62 on every captured state); a plant with three times the biomass does, and stays accurate."""
     e = golden("sbros_const_2_5")
     i = int(np.where(e["iv_kind"] == 1)[0][0])                         # aeration switch-on: So = 0, Kla > 0
@@ -552,7 +552,7 @@ def test_scheme1_takes_more_steps_where_four_would_be_unstable():
     x0[5] *= 3.0; x0[6] *= 3.0
     x2, n2 = O.reaction_interval(x0, span, kla, 0.0)
     exact = O.rk4(0, x0, span, 320, kla, 0.0)
-    assert 5 <= n2 <= 12 and gate(x2, exact).max() < 0.5, (n2, gate(x2, exact).max())
+    assert 5 <= n2 <= 14 and gate(x2, exact).max() < 0.5, (n2, gate(x2, exact).max())
     assert O.reaction_interval(x0, span, kla, 0.0, scheme=0)[1] == -1
     x0[5] *= 1e6                                                       # absurd: the count is capped, the call returns
     assert O.reaction_interval(x0, span, kla, 0.0)[1] == 64
@@ -602,4 +602,35 @@ def test_scheme1_on_the_intervals_of_the_per_cycle_env_fresh_and_carried_over(ta
         hist[n] = hist.get(n, 0) + 1
         count += 1
     assert count > 3500 and worst < 0.3, (count, worst)
-    assert set(hist) <= {1, 2, 4} and hist.get(4, 0) > 50          # knees are in the population
+    assert set(hist) <= {1, 2, 4, 5, 6} and hist.get(4, 0) > 50    # knees are in the population
+
+
+def test_scheme1_plan_on_states_far_from_the_reference_regime():
+    """A robustness probe of the plan, not a parity statement: 3 000 random plant states far beyond anything the fixtures hold
+    (sludge 0.4 - 3 x the reference's, substrate from exhausted to shock-loaded, oxygen from 0 to saturation, every Kla and EC;
+    scripts/analysis/plan_probe.py), one interval each against RK4 x 320.  Such states sit on several Monod knees at once and ten
+    RK4 substeps themselves miss the gate on ~2.4 % of them; scheme 1 must be no worse than that by more than a third, and must
+    not blow up where RK4 x 10 is fine (round 5: the first version of the plan took the oxygen rate at the START levels of Ss and
+    Snh and was unstable when carbon dosing raised Ss within the interval - 4 000 gates; the plan now projects them)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("plan_probe", os.path.join(ROOT, "scripts", "analysis", "plan_probe.py"))
+    pp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pp)
+    rs = np.random.RandomState(1)
+    span = (0.25 + P.T_DELTA) - 0.25
+    p1 = _scheme1_params()
+    g1, g0 = [], []
+    for _ in range(3000):
+        x, kla, ec = pp.sample(rs)
+        ex = O.rk4(0, x, span, 320, kla, ec)
+        if not (np.isfinite(ex).all() and (ex[[2, 4, 5, 8, 9, 10]] > -1e-9).all()):
+            continue                                        # the fine solution itself leaves the model's domain
+        g1.append(gate(O.reaction_interval(x, span, kla, ec, params=p1, scheme=1)[0], ex).max())
+        g0.append(gate(O.rk4(0, x, span, 10, kla, ec), ex).max())
+    g1, g0 = np.array(g1), np.array(g0)
+    assert len(g1) > 2800
+    assert (g1 > 1).sum() <= 1.35 * (g0 > 1).sum() + 5, ((g1 > 1).sum(), (g0 > 1).sum())          # measured 91 against 68
+    assert np.percentile(g1, 99) < 8 and g1.max() < 200                                             # measured 4.3 and 39 (RK4 x 10: 5.8, 3 000)
+    assert (g1[g0 < 0.1] > 30).sum() == 0                   # no blow-up where ten RK4 substeps are accurate (measured: worst 6.9)
