@@ -58,15 +58,16 @@ ALGO_BYTES_PER_ENV_STEP = 513          # x 112+112, ctrl
 HBM_PEAK_GBPS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 CALLS_PER_EPISODE = 463
 # float64 operations per RK4 substep, counted in the gfx950 ISA of the two substep loops of k_step: when no lane of the wave
-# doses carbon 159 FMA x 2 + 104 MUL + 4 ADD + 4 RCP = 430; with dosing (round 4: the scaled-mass loop, unrolled by two:
-# 346 x 2 + 216 + 20 + 8 per two substeps) 468 (rounds 2-3, concentration form: 552).  The loops only (no PIDs, reward,
+# doses carbon 155 FMA x 2 + 104 MUL + 8 ADD + 4 RCP = 426; with dosing (round 4: the scaled-mass loop, unrolled by two:
+# 338 x 2 + 216 + 28 + 8 per two substeps) 464 (rounds 2-3, concentration form: 552; until the library was built with
+# -ffp-contract=off the backend had turned four of the adds per substep into FMAs: 430 / 468 by this count, same instructions).  The loops only (no PIDs, reward,
 # observations): a LOWER bound of the work per env-step.  tests/test_isa_cpu.py asserts both figures against the compiler's output.
-FP64_FLOP_PER_SUBSTEP = {"plain": 430, "dosing": 468, "filling": 590}      # filling: k_cycle's / k_reset's loop, (426 x 2 + 229 + 88 + 12) / 2
+FP64_FLOP_PER_SUBSTEP = {"plain": 426, "dosing": 464, "filling": 586}      # filling: k_cycle's / k_reset's loop, (418 x 2 + 229 + 96 + 12) / 2
 SUBSTEPS = 10
 # cfg.scheme = 1 (round 5, the default): float64 operations of ONE step of the adaptive Butcher-5 integrator (six right-hand
-# sides), counted in the ISA of sbr_b5a's step loops (296 FMA x 2 + 169 MUL + 6 ADD + 6 RCP; with dosing 334 x 2 + 179 + 18 + 6);
+# sides), counted in the ISA of sbr_b5a's step loops (290 FMA x 2 + 169 MUL + 12 ADD + 6 RCP; with dosing 328 x 2 + 179 + 24 + 6);
 # tests/test_isa_cpu.py asserts both.  How many steps an interval takes is decided per env (1, 2 or 4).
-FP64_FLOP_PER_B5_STEP = {"plain": 773, "dosing": 871}
+FP64_FLOP_PER_B5_STEP = {"plain": 767, "dosing": 865}
 # vector float64 peak: 256 CUs x 4 SIMDs x 16 FMA lanes x 2 FLOP x 2.4 GHz = 78.6 TFLOP/s, i.e. half the 157.3 TFLOP/s float32
 # vector figure of /opt/skills/guides/MI355X_MICROARCH.md (the guide lists no float64 vector row); one wave64 FMA = 4 cycles
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -275,7 +276,7 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
             "note": "RK4 substep loops only, counted in the ISA (FMA = 2): a lower bound of the work"}
     if scheme == 1:       # the step count of every non-fill interval is decided per env; this path has no CPU sample to count them
         fp64 = {"achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "note": "cfg.scheme = 1: every one of the 528 intervals takes 1, 2 or 4 Butcher-5 steps (773 FLOP each) as each env's "
+                "note": "cfg.scheme = 1: every one of the 528 intervals takes 1, 2 or 4 Butcher-5 steps (767 FLOP each) as each env's "
                         "state demands; read issue_slot_frac (committed PMC profile) for utilisation"}
     rec, why = pmc_record(loaded_library_hash())
     traffic = None
@@ -566,6 +567,13 @@ def main():
     if rec and n_local != rec.get("envs_per_launch", 65536):
         rec, traffic_note = None, "the committed PMC profile is of %d envs per launch, this run has %d" % (rec.get("envs_per_launch", 65536), n_local)
     episode = None          # whole-episode launch time of the committed kernel trace of THIS library (hash-matched like traffic)
+    if rec:                 # ... and of this cfg.scheme: the profile round runs the default one (k_step<float, float, 256, false, SCH, WAVES>)
+        try:
+            rec_scheme = int(rec["kernel_trace"]["kernel"].split("<")[1].split(">")[0].split(",")[4])
+        except (KeyError, IndexError, ValueError):
+            rec_scheme = 1
+        if rec_scheme != scheme:
+            rec, traffic_note = None, "the committed PMC profile is of cfg.scheme = %d, this run has %d" % (rec_scheme, scheme)
     if rec and not fused and args.workload == "config2":
         traffic = rec["hbm_bytes_per_launch"]
         valu_per_wave = rec.get("valu_insts_per_wave")
@@ -594,7 +602,7 @@ def main():
     dosing_share = over_timed_calls("dosing_wave_share")
     waves = (n_local + 63) // 64
     if scheme == 1:
-        # scheme 1: the work per interval is decided per env (1, 2 or 4 Butcher-5 steps of 773 FLOP; with dosing 871); a
+        # scheme 1: the work per interval is decided per env (1, 2 or 4 Butcher-5 steps of 767 FLOP; with dosing 865); a
         # wavefront executes its slowest lane's count with the other lanes masked.  `achieved` counts the USEFUL work (the mean
         # count per env at the closed-reactor figure: a lower bound), `executed_flop_per_env_step` what the wavefronts issued.
         steps_lane, steps_wave = over_timed_calls("steps_lane_mean"), over_timed_calls("steps_wave_mean")
@@ -610,15 +618,15 @@ def main():
                         "sample of the same workload over the same calls of the episode (null with --no-cpu-baseline); scheme 0 "
                         "spent 4300 FLOP per env-step on the same intervals"}
     else:
-        # scheme 0: the RK4 substep loops only, ALL counted at the closed-reactor loop's 430 FLOP per substep - a lower bound.  A
-        # wave with at least one lane dosing carbon runs the dosing loop instead (468 FLOP per substep); how many do is a property
+        # scheme 0: the RK4 substep loops only, ALL counted at the closed-reactor loop's 426 FLOP per substep - a lower bound.  A
+        # wave with at least one lane dosing carbon runs the dosing loop instead (464 FLOP per substep); how many do is a property
         # of the policy, not of the phase (config.dosing_wave_call_share).
         flop_per_step = SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]
         tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12
         fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                 "flop_per_env_step": flop_per_step, "anoxic_share_of_timed_calls": frac_anoxic,
                 "note": "RK4 substep loops only, every call counted at the closed-reactor loop's ISA count (FMA = 2): a lower bound of "
-                        "the work (waves with a dosing lane run 468 instead of 430 FLOP per substep); one wave per SIMD issues a "
+                        "the work (waves with a dosing lane run 464 instead of 426 FLOP per substep); one wave per SIMD issues a "
                         "v_fma_f64 every 5.2 cycles and v_mul/v_add_f64 every 4.3 (scripts/probes/fp64_issue.hip), so ~0.8 of the "
                         "nominal peak is what a single resident wave can reach"}
     if valu_per_wave:
@@ -721,7 +729,7 @@ def main():
                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
                    "scheme": scheme, "library_source_hash": lib_hash,
                    "dosing_wave_call_share": dosing_share,
-                   "kernel": ("k_rollout<false,%d>" % scheme) if fused else "k_step<float,float,%d,false,%d>" % (64 if n_local <= 49152 else 256, scheme)},
+                   "kernel": ("k_rollout<false,%d>" % scheme) if fused else "k_step<float,float,%d,false,%d,%d>" % (64 if n_local <= 49152 else 256, scheme, 2 if (scheme == 1 and n_local > 65536) else 1)},
         "roofline": roofline,
         "env_status": {"near_pole_frac_last_episode": float(((st_bits & _capi.ST_NEAR_POLE) != 0).float().mean().item())
                        if state["episode"] > 2 else None,

@@ -18,7 +18,11 @@ LIB = os.path.join(_HERE, "lib", "libsbr_amd.so")
 HASH = LIB + ".srchash"
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's argument segment arrive in SGPRs at wave launch (gfx940+);
 # k_step's leading arguments are the pointers its first loads need (-0.5 us per launch at small batches, profiles/r02_notes.md)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
+# -ffp-contract=off: a multiply-add is fused where the source says __builtin_fma and nowhere else.  hipcc's default lets the
+# backend fuse a * b + c when it sees fit, which depends on the shape of the surrounding code: the two register budgets of
+# k_step (round 5) differed in three such places - by one ulp in the NO3-PID's integral from the first aerobic call on - where
+# the library promises the same bits for an env whatever batch it is stepped in.  No measurable cost (profiles/r05_notes.md).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off",
          "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
 #define SBR_PK_X6 3
 #define SBR_PK_KSUM (SBR_PK_X6 + SBR_NXD)
 #define SBR_NPARK 20
+#define SBR_NPARK_2W 32     // k_step<.., WAVES = 2>: + what the call keeps across the integration (SbrX6LdsT<true>)
 
 // One output row per lane (obs: 18 values, state: 15) -> the caller's row-major tensor.  A full wavefront owns 64
 // consecutive rows, i.e. ONE contiguous block of 64 x NV x sizeof(OutT) bytes (4608 B of float32 observations): the rows go
@@ -592,8 +593,14 @@ struct SbrTraceRec {
 #ifndef SBR_STEP_MIN_BLOCKS
 #define SBR_STEP_MIN_BLOCKS 1      // A/B builds: 2 caps k_step<.., 256, ..> at 256 registers (two waves per SIMD)
 #endif
-template <typename OutT, typename ActT, int BLK, bool OCI, int SCH>
-__global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
+// WAVES = 2 (scheme 1, launches with more wavefronts than the chip has SIMDs): the register budget of two resident waves per SIMD
+// (256).  The scheme-1 step loops need 320 registers with everything the call carries across them; this build parks that - 13
+// controller values per interval, 7 of the call, 19 around the idle phase of the done call - in the lane's LDS slots (64 KiB per
+// workgroup, two workgroups per CU) and forms the row addresses of its stores again afterwards instead of keeping them.
+// Same arithmetic, same bits.  Measured (profiles/r05_ab_two_waves.log): 65 536 envs 12.8 against 12.2 us per call (one wave per
+// SIMD either way: the host keeps WAVES = 1 there), 131 072 envs 20.1 against 23.3, 262 144 envs 36.1 against 44.5.
+template <typename OutT, typename ActT, int BLK, bool OCI, int SCH, int WAVES = 1>
+__global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BLOCKS) : 1) void k_step(double* __restrict__ bx, double* __restrict__ bctrl, int64_t bn,
                                                       const ActT* __restrict__ action, uint32_t flags, OutT* __restrict__ obs,
                                                       OutT* __restrict__ state, OutT* __restrict__ reward,
                                                       uint8_t* __restrict__ done, SbrPar p, SbrBuf b0) {
@@ -601,9 +608,10 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
     b.x = bx; b.ctrl = bctrl; b.n = bn;
     // wave-major: wave w owns park[w][slot][64], 20 slots x 512 B = 10 KiB; the region is reused for the output
     // transpose (64 float64 observation rows take 9216 B, float32 observation + state rows together 8448 B)
-    constexpr int NSLOT = SBR_NPARK;
+    constexpr bool PARK = WAVES == 2;
+    constexpr int NSLOT = PARK ? SBR_NPARK_2W : SBR_NPARK;
     __shared__ __attribute__((aligned(16))) double park[NSLOT * BLK];
-    const uint32_t l = threadIdx.x;
+    uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * BLK;
     if (i0 + l >= b.n) return;
 #ifdef SBR_STAMPS
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
     my[SBR_PK_RET * 64] = ret0; my[SBR_PK_META * 64] = meta0; my[SBR_PK_W8 * 64] = w8_0;
     // (The compiler sinks the action load into the `not done` branch below - one global_load behind the branch in the ISA.
     // Pinning it into the batch above was measured SLOWER, profiles/r04_ab_kernarg_warm_and_pinned_loads.log: left alone.)
-    SbrX6Lds x6{my + SBR_PK_X6 * 64};
+    SbrX6LdsT<PARK> x6{my + SBR_PK_X6 * 64};
     if (OCI) my[SBR_PK_KSUM * 64] = CTRL(R_KSUM);          // only this reward keeps the running sum of Kla
     x6.put(x);
     // the ring slot of the oldest entry = where this call's first Kla goes; the three entries behind it are the ones that leave
@@ -673,12 +681,23 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
 #ifndef SBR_STEP_LOOP
 #define SBR_STEP_LOOP false     // straight-line: the second interval of a phase-boundary call out of line (247 VGPRs; the loop form needs 278 with the dependent ring loads live across the integration)
 #endif
+        if constexpr (PARK) {
+            x6.park(13, lv[0]); x6.park(14, lv[1]); x6.park(15, lv[2]); x6.park(16, kla_before); x6.park(17, v0); x6.park(18, si0);
+            x6.park(19, xi0);
+        }
         sbr_run_intervals<SBR_STEP_LOOP, SCH>(p, c, x, a0, a1, x6, tr);
+        double kla_before_r = kla_before, v0_r = v0, si0_r = si0, xi0_r = xi0;
+        if constexpr (PARK) {
+            asm volatile("" : "+v"(l) : : "memory");  // the row addresses of the stores are formed again from here (not kept across the integration)
+            lv[0] = x6.unpark(13); lv[1] = x6.unpark(14); lv[2] = x6.unpark(15);
+            kla_before_r = x6.unpark(16); v0_r = x6.unpark(17); si0_r = x6.unpark(18); xi0_r = x6.unpark(19);
+        }
         SBR_STAMP(3, false);                  // PIDs + RK4 done
-        SbrHistInc hs{my[SBR_PK_W8 * 64], kla_before, {lv[0], lv[1], lv[2]}, 0.0, false};
-        x6.get(xa6);
+        SbrHistInc hs{my[SBR_PK_W8 * 64], kla_before_r, {lv[0], lv[1], lv[2]}, 0.0, false};
+        if constexpr (!PARK) x6.get(xa6);
         double ksum = OCI ? my[SBR_PK_KSUM * 64] : 0.0;
-        r = sbr_finish_step<OCI, SCH>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp);
+        r = sbr_finish_step<OCI, SCH, SbrHistInc, true, SbrX6LdsT<PARK>>(p, c, hs, x, xa6, t_obs, dn, qw, ksum, rp, &x6);
+        if constexpr (PARK) x6.get(xa6);              // after the terminal phases, which leave their pre-settle values in the slots
         SBR_STAMP(4, false);                  // reward (and, on the done call, the terminal phases) done
         // everything that reads the three ring entries loaded before the integration comes BEFORE the first store: the memory
         // counter retires in order, so a wait for one of those (long finished) loads placed after the plant stores would wait
@@ -690,7 +709,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? SBR_STEP_MIN_BLOCKS : 1) void k_s
         if (OCI) CTRL(R_KSUM) = ksum;
         // plant: V, Si and Xi only change with carbon dosing or in the terminal phases - skip their stores otherwise
         // (wave-uniform test: no lane of the wave changed them)
-        const bool inert_moved = (x[0] != v0) || (x[1] != si0) || (x[3] != xi0);
+        const bool inert_moved = (x[0] != v0_r) || (x[1] != si0_r) || (x[3] != xi0_r);
         if (__builtin_amdgcn_ballot_w64(inert_moved) != 0ull) {
             store_x(b, i0, l, x);
         } else {
@@ -1159,6 +1178,9 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
 #ifndef SBR_ONE_WAVE_MAX_ENVS
 #define SBR_ONE_WAVE_MAX_ENVS 98304     // up to 1.5 waves per SIMD the fused scheme-1 kernels run their uncapped-register build
 #endif
+#ifndef SBR_STEP_ONE_WAVE_MAX_ENVS
+#define SBR_STEP_ONE_WAVE_MAX_ENVS 65536    // = 1024 SIMDs x 64 lanes: above it the scheme-1 k_step runs its two-waves-per-SIMD build
+#endif
 #ifndef SBR_SMALL_BATCH
 #define SBR_SMALL_BATCH 49152       // up to this many envs k_step runs in 64-thread workgroups (measured: profiles/r02_ab_block.log)
 #endif
@@ -1169,6 +1191,11 @@ static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state
     if (e->n <= SBR_SMALL_BATCH)
         hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI, SCH>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
                            e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
+    else if (SCH == 1 && e->n > SBR_STEP_ONE_WAVE_MAX_ENVS)
+        hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI, SCH, SCH == 1 ? 2 : 1>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st,
+                           e->buf.x, e->buf.ctrl, e->buf.n, (const ActT*)action,
+                           flags | ((e->n >= SBR_STAGGER_MIN_ENVS && e->n <= SBR_STAGGER_MAX_ENVS) ? SBR_KF_STAGGER : 0u), (OutT*)obs,
+                           (OutT*)state, (OutT*)reward, done, e->par, e->buf);
     else
         hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI, SCH>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st, e->buf.x,
                            e->buf.ctrl, e->buf.n, (const ActT*)action,

@@ -595,6 +595,9 @@ SBR_DEV void sbr_take6(const double (&x)[SBR_NX], double (&x6)[SBR_NXD]) {
 }
 // where the start values of an interval are parked while the RK4 loop runs: registers, or this lane's LDS slots
 struct SbrX6Reg {
+    static constexpr bool kPark = false;
+    SBR_DEV void park(int, double) const {}
+    SBR_DEV double unpark(int) const { return 0.0; }
     double v[SBR_NXD];
     SBR_DEV void put(const double (&x)[SBR_NX]) { sbr_take6(x, v); }
     SBR_DEV void get(double (&o)[SBR_NXD]) const {
@@ -605,7 +608,13 @@ struct SbrX6Reg {
 #ifndef SBR_BLOCK
 #define SBR_BLOCK 256
 #endif
-struct SbrX6Lds {          // slot j of the lane lives at base[j * 64] inside its wave's region: conflict-free, 8-byte accesses
+template <bool PARK>
+struct SbrX6LdsT {         // slot j of the lane lives at base[j * 64] inside its wave's region: conflict-free, 8-byte accesses
+    // PARK (the two-waves-per-SIMD build of k_step): what the call keeps across the integration goes to the lane's slots behind
+    // the six start values (and the OCI sum) while the step loop runs, so that the loop has the registers
+    static constexpr bool kPark = PARK;
+    SBR_DEV void park(int j, double v) const { base[(SBR_NXD + 1 + j) * 64] = v; }
+    SBR_DEV double unpark(int j) const { return base[(SBR_NXD + 1 + j) * 64]; }
     double* base;
     SBR_DEV void put(const double (&x)[SBR_NX]) {
         base[0 * 64] = x[2]; base[1 * 64] = x[5]; base[2 * 64] = x[6]; base[3 * 64] = x[8]; base[4 * 64] = x[9];
@@ -616,6 +625,7 @@ struct SbrX6Lds {          // slot j of the lane lives at base[j * 64] inside it
         for (int j = 0; j < SBR_NXD; ++j) o[j] = base[j * 64];
     }
 };
+using SbrX6Lds = SbrX6LdsT<false>;
 
 // Sticky domain-of-validity bits (SBR_ST_* in sbr_amd.h), evaluated on the end state of an interval.  x < -K/2 is
 // "within 50 % of the pole of x/(K+x)".  Pure bookkeeping: nothing in the dynamics reads it.
@@ -686,6 +696,14 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
+    const double so_m1_in = c.so_m1, sno_m1_in = c.sno_m1, ec_last_in = c.ec_last;
+    if constexpr (X6::kPark) {
+        xs6.park(0, t1); xs6.park(1, c.so_m1); xs6.park(2, c.sno_m1); xs6.park(3, c.ie_do); xs6.park(4, c.ie_ec);
+        xs6.park(5, c.ec_last); xs6.park(6, ec); xs6.park(7, c.u_do); xs6.park(8, c.u_ec); xs6.park(9, kla);
+        xs6.park(10, c.knew[0]); xs6.park(11, span);
+        xs6.park(12, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows));       // three small integers: exact in a double
+        asm volatile("" ::: "memory");
+    }
     if constexpr (SCH == 1) {
 #ifdef SBR_B5_ONE_FORM
         sbr_b5a<true>(p, x, span, kla, ec);
@@ -698,6 +716,24 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
         if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_rk4<0>(p, x, h, p.substeps, kla, 0.0, nold);
         else sbr_rk4<1>(p, x, h, p.substeps, kla, ec, nold);
     }
+    if constexpr (X6::kPark) {
+        asm volatile("" ::: "memory");
+        const double t1_ = xs6.unpark(0), kla_ = xs6.unpark(9), ec_ = xs6.unpark(6);
+        const int pk = (int)xs6.unpark(12);
+        c.n_new = pk >> 16; c.st_new = (pk >> 4) & 0xfff; c.rows = pk & 15;
+        c.knew[0] = xs6.unpark(10);
+        if (c.n_new == 0) c.knew[0] = kla_; else c.knew[1] = kla_;
+        c.n_new += 1;
+        c.kla_last = kla_;
+        c.ec_prev = xs6.unpark(5); c.ec_last = ec_;
+        c.so_m2 = xs6.unpark(1); c.so_m1 = x[8];
+        c.sno_m2 = xs6.unpark(2); c.sno_m1 = x[9];
+        c.ie_do = xs6.unpark(3); c.ie_ec = xs6.unpark(4); c.u_do = xs6.unpark(7); c.u_ec = xs6.unpark(8);
+        c.t = t1_; c.span = xs6.unpark(11);
+        c.st_new |= sbr_status_bits(p, x);
+        return;
+    }
+    (void)so_m1_in; (void)sno_m1_in; (void)ec_last_in;
     if (c.n_new == 0) c.knew[0] = kla; else c.knew[1] = kla;      // n_new <= 2, see SbrCtl
     c.n_new += 1;
     c.kla_last = kla;
@@ -1000,9 +1036,10 @@ SBR_DEV double sbr_terminal(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_N
 // TERMINAL_INLINE = false leaves the terminal phases of the done call to the caller (the fused rollout runs them once, after its
 // loop over the calls: with them inside the loop the compiler keeps their working set alive across it - 3 % of the rollout's
 // time, profiles/r03_notes.md); the reward of a done call does not depend on them unless OCI.
-template <bool OCI, int SCH, typename H, bool TERMINAL_INLINE = true>
+template <bool OCI, int SCH, typename H, bool TERMINAL_INLINE = true, typename PK = SbrX6Reg>
 SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SBR_NX],
-                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp) {
+                               double (&xa6)[SBR_NXD], double& t_obs, bool& dn, double& qw, double& ksum, SbrRewardParts& rp,
+                               const PK* pk = nullptr) {
     const double kwin = hs.commit_and_window(c);
     double r;
     rp.eqi2 = 0.0; rp.ae = 0.0; rp.ec = 0.0;
@@ -1018,8 +1055,32 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
     if (c.t >= p.T5_end) {                                               // :1122
         dn = true;
         if ((TERMINAL_INLINE || OCI) && p.terminal) {
-            sbr_take6(x, xa6);
             const double snh_eff = x[10];            // solubles pass the settler unchanged: eff_component[3] (:2642)
+            if constexpr (PK::kPark) {
+                // the two-waves-per-SIMD build: nothing of the call is kept in registers across the idle phase's step loop
+                SbrX6LdsT<true> q = *pk;
+                q.put(x);                            // the caller fetches xa6 after this function
+                q.park(0, r); q.park(1, rp.eqi2); q.park(2, rp.ae); q.park(3, rp.ec); q.park(4, c.t); q.park(5, c.so_m1);
+                q.park(6, c.so_m2); q.park(7, c.sno_m1); q.park(8, c.sno_m2); q.park(9, c.ie_ec); q.park(10, c.ec_last);
+                q.park(11, c.ec_prev); q.park(12, c.u_ec); q.park(13, c.knew[0]); q.park(14, c.knew[1]); q.park(15, c.span);
+                q.park(16, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows)); q.park(17, snh_eff); q.park(18, ksum);
+                asm volatile("" ::: "memory");
+                qw = sbr_terminal<SCH>(p, c, hs, x);
+                asm volatile("" ::: "memory");
+                r = q.unpark(0); rp.eqi2 = q.unpark(1); rp.ae = q.unpark(2); rp.ec = q.unpark(3); c.t = q.unpark(4);
+                c.so_m1 = q.unpark(5); c.so_m2 = q.unpark(6); c.sno_m1 = q.unpark(7); c.sno_m2 = q.unpark(8);
+                c.ie_ec = q.unpark(9); c.ec_last = q.unpark(10); c.ec_prev = q.unpark(11); c.u_ec = q.unpark(12);
+                c.knew[0] = q.unpark(13); c.knew[1] = q.unpark(14); c.span = q.unpark(15);
+                const int pk3 = (int)q.unpark(16);
+                c.n_new = pk3 >> 16; c.st_new = (pk3 >> 4) & 0xfff; c.rows = pk3 & 15;
+                if (OCI) {
+                    ksum = q.unpark(18) + c.kla_last;
+                    r = sbr_reward_oci(p, 2, c.kla_last, ksum, qw, q.unpark(17));
+                }
+                t_obs = p.t_cycle;
+                return r;
+            }
+            sbr_take6(x, xa6);
             qw = sbr_terminal<SCH>(p, c, hs, x);
             if (OCI) {
                 ksum = ksum + c.kla_last;            // Sim_idle's Kla.append (:2578)

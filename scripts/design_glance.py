@@ -43,7 +43,7 @@ def table(tag):
         ("configs[2], `--steps 20 --warmup 5` (the driver's command: calls 5-24 of an episode, all anoxic)",
          "%.3ge9 env-steps/s, %.2f µs per step, %.2f µs per launch by events" % (drv["value"] / 1e9, drv["ms_per_step"] * 1e3, rd["avg_launch_us"]),
          "`%s_bench_config2_driver_style.json`" % tag),
-        ("`k_step<float,float,256,false,1>` per launch",
+        ("`k_step<float,float,256,false,1,1>` per launch",
          "%.2f µs (`rocprofv3 --kernel-trace --stats`, %d calls, whole episodes), %.2f µs by events over the %d timed launches"
          % (kt["average_ns"] / 1e3, kt["calls"], r2["avg_launch_us"], r2["launches_timed"]), "`%s_bench_config2_kernel_stats.csv`" % tag),
         ("prescribed roofline (513 B × 65 536 per launch ÷ 8 TB/s)",

@@ -1299,6 +1299,47 @@ def test_results_do_not_depend_on_wave_mates_or_shard_boundaries(G, tables):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reward", ["eqi_oci", "oci"])
+def test_parked_build_of_k_step_is_bit_identical_over_a_whole_episode(G, reward):
+    """Above 65 536 envs the scheme-1 k_step runs as k_step<..., WAVES = 2>: what a call keeps across the step loops is parked
+    in LDS (13 controller values per interval, 7 of the call, 19 around the idle phase of the done call) so that two waves fit a
+    SIMD.  Same arithmetic: a 65 536 + 320-env handle (ragged last workgroup) and handles of 4 096 envs (64-thread workgroups)
+    / 65 536 envs (256-thread workgroups, one wave per SIMD) on the same global env ids give the same outputs at sampled
+    calls, at the phase-boundary calls (two intervals) and at the done call (terminal phases), and the same plant, controller
+    rows and returns after the episode - bit for bit, under the reference's reward and the OCI reward (whose running sum takes
+    part in the parking)."""
+    n_big, calls = 65536 + 320, 463
+    gen = torch.Generator(device="cuda"); gen.manual_seed(31)
+    pool = torch.rand(16, n_big, 2, device="cuda", generator=gen) * torch.tensor([8.0, 15.0], device="cuda")
+    pool[:, ::3, 1] = 0.0                                              # a third of the lanes doses carbon in the anoxic phases
+    scen = (torch.arange(n_big, device="cuda") % 8).to(torch.int32)
+    views = {"small": (n_big - 4096, n_big), "one_wave": (0, 65536)}
+    big = G.SbrOSVec(n_big, reward=reward)
+    envs = {k: G.SbrOSVec(hi - lo, first_env_id=lo, reward=reward) for k, (lo, hi) in views.items()}
+    ob = big.reset(seed=17, scenario=scen)
+    for k, (lo, hi) in views.items():
+        assert torch.equal(envs[k].reset(seed=17, scenario=scen[lo:hi].contiguous()), ob[lo:hi])
+    n_done = 0
+    for c in range(calls):
+        a = pool[c & 15]
+        o, s_, r, d = big.step(a)
+        check = c % 29 == 0 or c in (45, 46, 47, 276, 277, 278, 279) or c >= calls - 2
+        for k, (lo, hi) in views.items():
+            o2, s2, r2, d2 = envs[k].step(a[lo:hi].contiguous())
+            if check:
+                assert torch.equal(o2, o[lo:hi]) and torch.equal(s2, s_[lo:hi]) and torch.equal(r2, r[lo:hi]) and torch.equal(d2, d[lo:hi]), (k, c)
+        n_done += int(d.all())
+    assert n_done == 1 and bool(d.all())                               # the last call was the done call of every env
+    xb, cb = big.get_state()
+    for k, (lo, hi) in views.items():
+        x2, c2 = envs[k].get_state()
+        assert torch.equal(x2, xb[:, lo:hi]) and torch.equal(c2, cb[:, lo:hi]), k
+        assert torch.equal(envs[k].episode_returns(), big.episode_returns()[lo:hi]), k
+        envs[k].close()
+    big.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("substeps", [5, 20])
 def test_other_substep_counts_against_oracle(G, tables, substeps):
     """cfg.substeps is a parameter of both the kernels and the oracle (the step h = span / substeps reaches the device as a
@@ -1578,7 +1619,7 @@ def test_bench_line_contract(force_dist):
     assert abs(r["frac_wall"] - wall) < 1e-9 and r["frac"] <= wall * 1.05 and r["frac"] <= r["frac_timed_launches"] * 1.02
     assert r["frac_is"] in ("frac_episode", "frac_wall") and abs(r["frac"] - r[r["frac_is"]]) < 1e-12
     assert ("frac_episode" in r) and (r["frac_episode"] is None or 0.1 < r["frac_episode"] < 0.6) and r["frac_episode_source"]
-    assert c["scheme"] == 1 and c["step_issue"].startswith("HIP-graph") and c["kernel"] == "k_step<float,float,256,false,1>"
+    assert c["scheme"] == 1 and c["step_issue"].startswith("HIP-graph") and c["kernel"] == "k_step<float,float,256,false,1,1>"
     assert c["dosing_wave_call_share"] is None           # counted by the CPU baseline's pass, which this run skips
     # ... and so does the no-overlap bound they are to be read against (memory at the roofline's rate + arithmetic + launch floor),
     # from a committed record of this library (None when there is none)
