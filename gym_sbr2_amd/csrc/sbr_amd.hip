@@ -349,7 +349,12 @@ __global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, c
         ld[0] = qin * p.inv_T_fill;
     } else {
 #pragma unroll
-        for (int j = 0; j < SBR_NX; ++j) x0[j] = p.x0[j];
+        for (int j = 0; j < SBR_NX; ++j) {
+            x0[j] = p.x0[j];
+            // held in VGPRs from here on: read again from the argument registers after the fill loop (the observation's start
+            // values, So[-2], Sno[-2]) they kept 17 SGPRs too many alive across it - spill slots, i.e. a scratch segment
+            asm volatile("" : "+v"(x0[j]));
+        }
         ld[0] = p.load0;                                             // :287
     }
 #pragma unroll

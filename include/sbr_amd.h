@@ -124,8 +124,9 @@ typedef struct sbr_config {
                                   1 (default, round 5): Butcher's fifth-order scheme with 1, 2 or 4 steps chosen per env and
                                   interval from the env's own state - dissolved oxygen, the system's one stiff mode, is held
                                   where it is slaved to zero, and an env whose oxygen mode is stiffer than the reference plant's
-                                  takes more steps: ~10 evaluations per interval, and closer to the
-                                  reference's trajectories than scheme 0 (closed loop, worst 0.41 of the 1e-5 gate against 0.51).
+                                  takes more steps, as does one whose substrate, ammonia or nitrate moves across its
+                                  half-saturation constant within the interval: ~10 evaluations per interval, and closer to the
+                                  reference's trajectories than scheme 0 (closed loop, worst 0.36 of the 1e-5 gate against 0.51).
                                   `substeps` then only sets the fill intervals of sbr_cycle_step; the idle phase is cut into
                                   ceil(rows / 10) macro intervals.  sbr_eval_substeps replays RK4 nodes under either scheme. */
     int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; must be 0 */

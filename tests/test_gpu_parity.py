@@ -1316,6 +1316,8 @@ def test_parked_build_of_k_step_is_bit_identical_over_a_whole_episode(G, reward)
     views = {"small": (n_big - 4096, n_big), "one_wave": (0, 65536)}
     big = G.SbrOSVec(n_big, reward=reward)
     envs = {k: G.SbrOSVec(hi - lo, first_env_id=lo, reward=reward) for k, (lo, hi) in views.items()}
+    # the trajectory export (which also switches the kernels to the So[-2] / Sno[-2] rows) of the first 96 envs, on both builds
+    tr_big, tr_one = big.enable_trace(96, calls), envs["one_wave"].enable_trace(96, calls)
     ob = big.reset(seed=17, scenario=scen)
     for k, (lo, hi) in views.items():
         assert torch.equal(envs[k].reset(seed=17, scenario=scen[lo:hi].contiguous()), ob[lo:hi])
@@ -1330,6 +1332,7 @@ def test_parked_build_of_k_step_is_bit_identical_over_a_whole_episode(G, reward)
                 assert torch.equal(o2, o[lo:hi]) and torch.equal(s2, s_[lo:hi]) and torch.equal(r2, r[lo:hi]) and torch.equal(d2, d[lo:hi]), (k, c)
         n_done += int(d.all())
     assert n_done == 1 and bool(d.all())                               # the last call was the done call of every env
+    assert torch.equal(torch.nan_to_num(tr_big, nan=-7.0), torch.nan_to_num(tr_one, nan=-7.0)) and not torch.isnan(tr_big[:, 0]).any()
     xb, cb = big.get_state()
     for k, (lo, hi) in views.items():
         x2, c2 = envs[k].get_state()

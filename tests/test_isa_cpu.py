@@ -174,6 +174,10 @@ def test_k_step_has_no_scratch_no_division_on_the_ordinary_path(asm):
     assert meta(asm, K_STEP_RK4, "vgpr_count") <= 256 and meta(asm, K_STEP_RK4, "private_segment_fixed_size") == 0    # scheme 0: as shipped in round 4
     assert meta(asm, K_CYCLE_RK4, "vgpr_count") <= 256 and meta(asm, K_ROLLOUT_2W, "vgpr_count") <= 256
     assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") == 0 and meta(asm, K_CYCLE, "private_segment_fixed_size") == 0
+    # k_reset without a scratch segment (its 68 B were spill slots of 17 scalar registers: the start state read
+    # again from the argument registers after the fill loop; held in VGPRs now)
+    for k in (K_RESET, K_RESET_CARRY, K_CYCLE_RESET):
+        assert meta(asm, k, "private_segment_fixed_size") == 0 and f64_mix(instructions(kernel_text(asm, k)))["scratch"] == 0, k
     small = f64_mix(instructions(kernel_text(asm, K_STEP_SMALL)))
     assert small["scratch"] == 0 and small["div"] <= 8 and meta(asm, K_STEP_SMALL, "private_segment_fixed_size") == 0
 
