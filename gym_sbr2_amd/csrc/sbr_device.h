@@ -696,12 +696,14 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     double nold[SBR_NX];
 #pragma unroll
     for (int i = 0; i < SBR_NX; ++i) nold[i] = 0.0;
-    const double so_m1_in = c.so_m1, sno_m1_in = c.sno_m1, ec_last_in = c.ec_last;
+    // what the rest of the call needs of this interval; the two-waves-per-SIMD build of k_step (X6::kPark) keeps none of it - nor
+    // the controller state - in registers while the step loop runs: 13 values go to the lane's LDS slots and come back
+    double t1r = t1, klar = kla, ecr = ec, spanr = span;
     if constexpr (X6::kPark) {
         xs6.park(0, t1); xs6.park(1, c.so_m1); xs6.park(2, c.sno_m1); xs6.park(3, c.ie_do); xs6.park(4, c.ie_ec);
         xs6.park(5, c.ec_last); xs6.park(6, ec); xs6.park(7, c.u_do); xs6.park(8, c.u_ec); xs6.park(9, kla);
         xs6.park(10, c.knew[0]); xs6.park(11, span);
-        xs6.park(12, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows));       // three small integers: exact in a double
+        xs6.park(12, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows));       // three small integers (rows <= 10, status < 8): exact
         asm volatile("" ::: "memory");
     }
     if constexpr (SCH == 1) {
@@ -718,29 +720,20 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     }
     if constexpr (X6::kPark) {
         asm volatile("" ::: "memory");
-        const double t1_ = xs6.unpark(0), kla_ = xs6.unpark(9), ec_ = xs6.unpark(6);
+        t1r = xs6.unpark(0); klar = xs6.unpark(9); ecr = xs6.unpark(6); spanr = xs6.unpark(11);
         const int pk = (int)xs6.unpark(12);
         c.n_new = pk >> 16; c.st_new = (pk >> 4) & 0xfff; c.rows = pk & 15;
         c.knew[0] = xs6.unpark(10);
-        if (c.n_new == 0) c.knew[0] = kla_; else c.knew[1] = kla_;
-        c.n_new += 1;
-        c.kla_last = kla_;
-        c.ec_prev = xs6.unpark(5); c.ec_last = ec_;
-        c.so_m2 = xs6.unpark(1); c.so_m1 = x[8];
-        c.sno_m2 = xs6.unpark(2); c.sno_m1 = x[9];
-        c.ie_do = xs6.unpark(3); c.ie_ec = xs6.unpark(4); c.u_do = xs6.unpark(7); c.u_ec = xs6.unpark(8);
-        c.t = t1_; c.span = xs6.unpark(11);
-        c.st_new |= sbr_status_bits(p, x);
-        return;
+        c.so_m1 = xs6.unpark(1); c.sno_m1 = xs6.unpark(2); c.ie_do = xs6.unpark(3); c.ie_ec = xs6.unpark(4);
+        c.ec_last = xs6.unpark(5); c.u_do = xs6.unpark(7); c.u_ec = xs6.unpark(8);
     }
-    (void)so_m1_in; (void)sno_m1_in; (void)ec_last_in;
-    if (c.n_new == 0) c.knew[0] = kla; else c.knew[1] = kla;      // n_new <= 2, see SbrCtl
+    if (c.n_new == 0) c.knew[0] = klar; else c.knew[1] = klar;    // n_new <= 2, see SbrCtl
     c.n_new += 1;
-    c.kla_last = kla;
-    c.ec_prev = c.ec_last; c.ec_last = ec;
+    c.kla_last = klar;
+    c.ec_prev = c.ec_last; c.ec_last = ecr;
     c.so_m2 = c.so_m1; c.so_m1 = x[8];
     c.sno_m2 = c.sno_m1; c.sno_m1 = x[9];
-    c.t = t1; c.span = span;
+    c.t = t1r; c.span = spanr;
     c.st_new |= sbr_status_bits(p, x);
 }
 
