@@ -32,6 +32,9 @@ for n in 32768 131072 262144; do
   timeout -k 10 300 python3 bench.py --envs-per-gpu $n --no-cpu-baseline > profiles/${tag}_bench_config2_n$n.json 2> $out/bench_n$n.err
   echo "bench n=$n: $(cut -c1-120 profiles/${tag}_bench_config2_n$n.json)"
 done
+# the two-waves-per-SIMD build of k_step under the kernel trace (whole episodes at 262144 envs per launch)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_n262144 -o run --output-format csv -- python3 bench.py --envs-per-gpu 262144 --no-cpu-baseline > $out/bench_n262144_profiled.json 2> $out/trace_n262144.err \
+  && head -8 $(find $out/trace_n262144 -name "*kernel_stats.csv" | head -1) | cut -c1-400 > profiles/${tag}_bench_config2_n262144_kernel_stats.csv || echo "n262144 trace failed (optional)"
 # cfg.scheme = 0 (ten RK4 substeps per interval: what rounds 1-4 shipped) on the same box, same workload
 timeout -k 10 300 python3 bench.py --scheme 0 --no-cpu-baseline > profiles/${tag}_bench_config2_scheme0.json 2> $out/bench_scheme0.err
 timeout -k 10 300 python3 bench.py --scheme 0 --workload config5 --no-cpu-baseline > profiles/${tag}_bench_config5_scheme0.json 2>> $out/bench_scheme0.err
