@@ -273,8 +273,9 @@ SBR_DEV int sbr_scenario_draw(uint64_t seed, uint64_t gid) {
 }
 
 // copy the influent tables [2][8][14][48] from HBM into the padded LDS image (whole workgroup; caller synchronises)
+template <int BLK = SBR_RESET_BLOCK>
 SBR_DEV void stage_tables(double* lds, const double* __restrict__ tables) {
-    for (int k = threadIdx.x; k < 2 * kTableDoubles; k += SBR_RESET_BLOCK)
+    for (int k = threadIdx.x; k < 2 * kTableDoubles; k += BLK)
         lds[k + 2 * (k / (SBR_NSERIES * SBR_NSAMP))] = tables[k];
 }
 
@@ -320,19 +321,21 @@ SBR_DEV int pick_scenario(const SbrPar& p, const int32_t* __restrict__ scenario,
 // ------------------------------------------------------------------------------------------- reset
 // SbrOS.reset :168-438.  Influent tables (means, stds: 2 x 42 KiB) are staged in LDS once per
 // workgroup; every lane then walks the 48 samples of ITS scenario (same scenario => LDS broadcast).
-template <typename OutT, bool CARRY>
-__global__ __launch_bounds__(SBR_RESET_BLOCK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
+// BLK = 512 (launches with more wavefronts than the device has SIMDs): the 84 KiB of tables allow one workgroup per CU, so eight
+// waves per workgroup are what puts two on a SIMD.
+template <typename OutT, bool CARRY, int BLK = SBR_RESET_BLOCK>
+__global__ __launch_bounds__(BLK) void k_reset(SbrPar p, SbrBuf b, const double* __restrict__ tables,
                                                     uint64_t seed, const int32_t* __restrict__ scenario,
                                                     const double* __restrict__ rnd, const double* __restrict__ influent,
                                                     const uint8_t* __restrict__ mask, OutT* __restrict__ obs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][8][SBR_TSTRIDE]
     const bool need_tables = (influent == nullptr);
     if (need_tables) {
-        stage_tables(lds, tables);
+        stage_tables<BLK>(lds, tables);
         __syncthreads();
     }
     const uint32_t l = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * SBR_RESET_BLOCK, i = i0 + l;
+    const int64_t i0 = (int64_t)blockIdx.x * BLK, i = i0 + l;
     if (i >= b.n) return;
     if (mask != nullptr && mask[i] == 0) return;
     const uint64_t gid = (uint64_t)(b.first_env_id + i);
@@ -1063,6 +1066,7 @@ struct sbr_env {
     SbrPar par;
     SbrBuf buf{};
     double* tables = nullptr;     // [2][8][14][48] on the device
+    int64_t one_wave_envs = 65536; // lanes of one wave per SIMD on this device: CUs x 4 SIMDs x 64 (MI355X: 256 CUs)
     bool have_tables = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
@@ -1183,8 +1187,12 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
 #ifndef SBR_ONE_WAVE_MAX_ENVS
 #define SBR_ONE_WAVE_MAX_ENVS 98304     // up to 1.5 waves per SIMD the fused scheme-1 kernels run their uncapped-register build
 #endif
-#ifndef SBR_STEP_ONE_WAVE_MAX_ENVS
-#define SBR_STEP_ONE_WAVE_MAX_ENVS 65536    // = 1024 SIMDs x 64 lanes: above it the scheme-1 k_step runs its two-waves-per-SIMD build
+// A launch with more wavefronts than the device has SIMDs (MI355X: 1024 SIMDs x 64 lanes = 65536 envs; a partitioned device has
+// fewer) runs the two-waves-per-SIMD build of the scheme-1 k_step.  A/B builds fix the threshold with -DSBR_STEP_ONE_WAVE_MAX_ENVS=n.
+#ifdef SBR_STEP_ONE_WAVE_MAX_ENVS
+#define SBR_STEP_ONE_WAVE_ENVS(e) ((int64_t)(SBR_STEP_ONE_WAVE_MAX_ENVS))
+#else
+#define SBR_STEP_ONE_WAVE_ENVS(e) ((e)->one_wave_envs)
 #endif
 #ifndef SBR_SMALL_BATCH
 #define SBR_SMALL_BATCH 49152       // up to this many envs k_step runs in 64-thread workgroups (measured: profiles/r02_ab_block.log)
@@ -1196,7 +1204,7 @@ static void launch_step_k(sbr_env* e, const void* action, void* obs, void* state
     if (e->n <= SBR_SMALL_BATCH)
         hipLaunchKernelGGL((k_step<OutT, ActT, 64, OCI, SCH>), dim3((unsigned)((e->n + 63) / 64)), dim3(64), 0, st, e->buf.x, e->buf.ctrl,
                            e->buf.n, (const ActT*)action, flags, (OutT*)obs, (OutT*)state, (OutT*)reward, done, e->par, e->buf);
-    else if (SCH == 1 && e->n > SBR_STEP_ONE_WAVE_MAX_ENVS)
+    else if (SCH == 1 && e->n > SBR_STEP_ONE_WAVE_ENVS(e))
         hipLaunchKernelGGL((k_step<OutT, ActT, 256, OCI, SCH, SCH == 1 ? 2 : 1>), dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, st,
                            e->buf.x, e->buf.ctrl, e->buf.n, (const ActT*)action,
                            flags | ((e->n >= SBR_STAGGER_MIN_ENVS && e->n <= SBR_STAGGER_MAX_ENVS) ? SBR_KF_STAGGER : 0u), (OutT*)obs,
@@ -1323,6 +1331,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
         sbr_destroy(e);
         return fail(nullptr, SBR_ERR_NO_DEVICE, m);
     }
+    e->one_wave_envs = (int64_t)prop.multiProcessorCount * 4 * 64;
     const size_t nb = (size_t)n_envs * sizeof(double);
     CREATE_TRY(hipMalloc(&e->buf.x, SBR_NX * nb));
     CREATE_TRY(hipMalloc(&e->buf.ctrl, R_NROWS * nb));
@@ -1386,12 +1395,16 @@ static int reset_impl(sbr_env* e, bool carry, uint64_t seed, const int32_t* scen
     ON_DEVICE(e);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = influent ? 0 : kLdsTableDoubles * sizeof(double);
-    const dim3 grid((unsigned)((e->n + SBR_RESET_BLOCK - 1) / SBR_RESET_BLOCK)), blk(SBR_RESET_BLOCK);
-#define RESET_LAUNCH(T, C) hipLaunchKernelGGL((k_reset<T, C>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, rnd, \
-                                              influent, mask, (T*)obs)
+    const bool wide = e->n > e->one_wave_envs;           // more waves than SIMDs: 512-thread workgroups, two waves per SIMD
+    const int bs = wide ? 512 : SBR_RESET_BLOCK;
+    const dim3 grid((unsigned)((e->n + bs - 1) / bs)), blk(bs);
+#define RESET_LAUNCH_B(T, C, B) hipLaunchKernelGGL((k_reset<T, C, B>), grid, blk, lds, st, e->par, e->buf, e->tables, seed, scenario, \
+                                                   rnd, influent, mask, (T*)obs)
+#define RESET_LAUNCH(T, C) do { if (wide) RESET_LAUNCH_B(T, C, 512); else RESET_LAUNCH_B(T, C, SBR_RESET_BLOCK); } while (0)
     if (e->cfg.out_f64) { if (carry) RESET_LAUNCH(double, true); else RESET_LAUNCH(double, false); }
     else { if (carry) RESET_LAUNCH(float, true); else RESET_LAUNCH(float, false); }
 #undef RESET_LAUNCH
+#undef RESET_LAUNCH_B
     HIP_TRY(e, hipGetLastError());
     return SBR_OK;
 }

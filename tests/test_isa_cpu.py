@@ -21,8 +21,9 @@ K_ROLLOUT_2W = "_Z9k_rolloutILb0ELi1ELi2EE"
 K_ROLLOUT_RK4 = "_Z9k_rolloutILb0ELi0ELi2EE"
 K_CYCLE = "_Z7k_cycleIffLi1ELi1EE"
 K_CYCLE_RK4 = "_Z7k_cycleIffLi0ELi2EE"
-K_RESET = "_Z7k_resetIfLb0EE"
-K_RESET_CARRY = "_Z7k_resetIfLb1EE"
+K_RESET = "_Z7k_resetIfLb0ELi256EE"
+K_RESET_CARRY = "_Z7k_resetIfLb1ELi256EE"
+K_RESET_WIDE = "_Z7k_resetIfLb0ELi512EE"      # above one wave per SIMD: 512-thread workgroups (one 84 KiB table copy per CU, two waves per SIMD)
 K_CYCLE_RESET = "_Z13k_cycle_resetIfLb0EE"
 
 
@@ -176,7 +177,8 @@ def test_k_step_has_no_scratch_no_division_on_the_ordinary_path(asm):
     assert meta(asm, K_ROLLOUT, "private_segment_fixed_size") == 0 and meta(asm, K_CYCLE, "private_segment_fixed_size") == 0
     # k_reset without a scratch segment (its 68 B were spill slots of 17 scalar registers: the start state read
     # again from the argument registers after the fill loop; held in VGPRs now)
-    for k in (K_RESET, K_RESET_CARRY, K_CYCLE_RESET):
+    assert meta(asm, K_RESET_WIDE, "vgpr_count") <= 256
+    for k in (K_RESET, K_RESET_CARRY, K_RESET_WIDE, K_CYCLE_RESET):
         assert meta(asm, k, "private_segment_fixed_size") == 0 and f64_mix(instructions(kernel_text(asm, k)))["scratch"] == 0, k
     small = f64_mix(instructions(kernel_text(asm, K_STEP_SMALL)))
     assert small["scratch"] == 0 and small["div"] <= 8 and meta(asm, K_STEP_SMALL, "private_segment_fixed_size") == 0
