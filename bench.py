@@ -199,6 +199,19 @@ def larger_batches(lib_hash, profiles_dir=None):
         r = rec["roofline"]
         out[str(n)] = {"frac": r["frac"], "env_steps_per_s": rec["value"], "us_per_launch": rec["ms_per_step"] * 1e3,
                        "file": os.path.relpath(path, ROOT)}
+        # the same round's rocprofv3 --kernel-trace --stats of that run, when scripts/profile_round.sh took one: the step kernel
+        # alone, averaged over every launch of whole episodes (the wall-clock figure above also holds the resets)
+        stats = path[:-len(".json")] + "_kernel_stats.csv"
+        if os.path.exists(stats):
+            import csv
+            with open(stats) as f:
+                for row in csv.DictReader(f):
+                    if "k_step<" in row.get("Name", ""):
+                        avg = float(row["AverageNs"])
+                        out[str(n)].update({"kernel_trace_us_per_launch": avg * 1e-3, "kernel_trace_calls": int(row["Calls"]),
+                                            "frac_kernel_trace": n * ALGO_BYTES_PER_ENV_STEP / (avg * 1e-9) / 1e9 / HBM_PEAK_GBPS,
+                                            "kernel_trace_file": os.path.relpath(stats, ROOT)})
+                        break
     return out or None
 
 
