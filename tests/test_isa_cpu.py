@@ -155,6 +155,14 @@ def test_butcher5_step_loops(asm):
     assert len(instructions(kernel_text(asm, K_STEP))) < 0.8 * 11200      # 7 614 instructions; 11 142 with both schemes in one kernel
 
 
+def test_fused_multiply_adds_are_the_ones_the_source_spells_out():
+    """The library promises the same bits for an env whatever batch (i.e. whichever instantiation of a kernel) it is stepped in.
+    With hipcc's default -ffp-contract=fast the backend fuses a * b + c where it sees fit, and it saw fit in three more places of
+    k_step<..., WAVES = 2> than of k_step<..., WAVES = 1> (one ulp in the NO3-PID's integral; found by the GPU bit-identity test
+    of the two).  The build flag is part of the contract."""
+    assert "-ffp-contract=off" in B.FLAGS and "-fno-fast-math" in B.FLAGS
+
+
 def test_k_step_has_no_scratch_no_division_on_the_ordinary_path(asm):
     ins = instructions(kernel_text(asm, K_STEP))
     m = f64_mix(ins)
