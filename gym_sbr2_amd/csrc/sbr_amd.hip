@@ -618,6 +618,8 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BL
     // transpose (64 float64 observation rows take 9216 B, float32 observation + state rows together 8448 B)
     constexpr bool PARK = WAVES == 2;
     constexpr int NSLOT = PARK ? SBR_NPARK_2W : SBR_NPARK;
+    // parked values: slots SBR_PK_X6 + SBR_NXD + 1 + j, j < 20 (13 per interval + 7 of the call; 19 around the terminal phases)
+    static_assert(!PARK || SBR_NPARK_2W >= SBR_PK_X6 + SBR_NXD + 1 + 20, "the LDS region of the two-waves build is too small for its parked values");
     __shared__ __attribute__((aligned(16))) double park[NSLOT * BLK];
     uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * BLK;
@@ -1184,8 +1186,11 @@ static void derive_params(const sbr_config& c, SbrPar& p) {
     }
 }
 
-#ifndef SBR_ONE_WAVE_MAX_ENVS
-#define SBR_ONE_WAVE_MAX_ENVS 98304     // up to 1.5 waves per SIMD the fused scheme-1 kernels run their uncapped-register build
+// up to 1.5 waves per SIMD (MI355X: 98304 envs) the fused scheme-1 kernels run their uncapped-register build
+#ifdef SBR_ONE_WAVE_MAX_ENVS
+#define SBR_FUSED_ONE_WAVE_ENVS(e) ((int64_t)(SBR_ONE_WAVE_MAX_ENVS))
+#else
+#define SBR_FUSED_ONE_WAVE_ENVS(e) ((e)->one_wave_envs + (e)->one_wave_envs / 2)
 #endif
 // A launch with more wavefronts than the device has SIMDs (MI355X: 1024 SIMDs x 64 lanes = 65536 envs; a partitioned device has
 // fewer) runs the two-waves-per-SIMD build of the scheme-1 k_step.  A/B builds fix the threshold with -DSBR_STEP_ONE_WAVE_MAX_ENVS=n.
@@ -1468,7 +1473,7 @@ int sbr_cycle_step(sbr_env* e, const void* action, void* obs, void* reward, doub
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid = grid_for(e->n), blk(SBR_BLOCK);
 #define CSTEP1(T, A, S, W) hipLaunchKernelGGL((k_cycle<T, A, S, W>), grid, blk, 0, st, e->par, e->buf, (const A*)action, (T*)obs, (T*)reward, diag)
-#define CSTEP(T, A) do { if (e->cfg.scheme == 1) { if (e->n <= SBR_ONE_WAVE_MAX_ENVS) CSTEP1(T, A, 1, 1); else CSTEP1(T, A, 1, 2); } \
+#define CSTEP(T, A) do { if (e->cfg.scheme == 1) { if (e->n <= SBR_FUSED_ONE_WAVE_ENVS(e)) CSTEP1(T, A, 1, 1); else CSTEP1(T, A, 1, 2); } \
                          else CSTEP1(T, A, 0, 2); } while (0)
     if (e->cfg.out_f64) { if (e->cfg.act_f64) CSTEP(double, double); else CSTEP(double, float); }
     else { if (e->cfg.act_f64) CSTEP(float, double); else CSTEP(float, float); }
@@ -1483,7 +1488,7 @@ int sbr_rollout(sbr_env* e, int32_t n_steps, uint64_t policy_seed, double* retur
     ON_DEVICE(e);
 #define ROLL(O, S, W) hipLaunchKernelGGL((k_rollout<O, S, W>), grid_for(e->n), dim3(SBR_BLOCK), 0, (hipStream_t)stream, e->par, e->buf, \
                                          n_steps, policy_seed, returns, actions_out)
-    const bool one_wave = e->cfg.scheme == 1 && e->n <= SBR_ONE_WAVE_MAX_ENVS;
+    const bool one_wave = e->cfg.scheme == 1 && e->n <= SBR_FUSED_ONE_WAVE_ENVS(e);
     if (e->cfg.reward_kind == 2) { if (e->cfg.scheme == 1) { if (one_wave) ROLL(true, 1, 1); else ROLL(true, 1, 2); } else ROLL(true, 0, 2); }
     else { if (e->cfg.scheme == 1) { if (one_wave) ROLL(false, 1, 1); else ROLL(false, 1, 2); } else ROLL(false, 0, 2); }
 #undef ROLL

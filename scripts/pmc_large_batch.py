@@ -25,7 +25,9 @@ def pick(c, frag):
     return [k for k in c if frag in k][0]
 
 
-res = {"envs_per_launch": n}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gym_sbr2_amd import build as _b  # noqa: E402
+res = {"envs_per_launch": n, "library_source_hash": open(_b.HASH).read().strip() if os.path.exists(_b.HASH) else None}
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     c = rows(sub)[name]
     copies = [v for k in c if "direct_copy" in k or "copyBuffer" in k for v in c[k].values() if v > 0]

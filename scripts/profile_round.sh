@@ -35,6 +35,12 @@ done
 # the two-waves-per-SIMD build of k_step under the kernel trace (whole episodes at 262144 envs per launch)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_n262144 -o run --output-format csv -- python3 bench.py --envs-per-gpu 262144 --no-cpu-baseline > $out/bench_n262144_profiled.json 2> $out/trace_n262144.err \
   && head -8 $(find $out/trace_n262144 -name "*kernel_stats.csv" | head -1) | cut -c1-400 > profiles/${tag}_bench_config2_n262144_kernel_stats.csv || echo "n262144 trace failed (optional)"
+# ... and under the counters (separate passes again): traffic and issue activity with two waves on a SIMD
+( export PMC_ENVS=262144; o=$out/pmc_n262144; mkdir -p $o
+  timeout -k 10 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $o/pmc_fetch -o run --output-format csv -- python3 scripts/pmc_workload.py > $o/f.json 2> $o/f.err \
+  && timeout -k 10 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $o/pmc_write -o run --output-format csv -- python3 scripts/pmc_workload.py > $o/w.json 2> $o/w.err \
+  && timeout -k 10 250 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace -d $o/pmc_sq -o run --output-format csv -- python3 scripts/pmc_workload.py > $o/s.json 2> $o/s.err \
+  && python3 scripts/pmc_large_batch.py $o 262144 > profiles/${tag}_pmc_n262144.json ) || echo "PMC passes at 262144 envs failed (optional)"
 # cfg.scheme = 0 (ten RK4 substeps per interval: what rounds 1-4 shipped) on the same box, same workload
 timeout -k 10 300 python3 bench.py --scheme 0 --no-cpu-baseline > profiles/${tag}_bench_config2_scheme0.json 2> $out/bench_scheme0.err
 timeout -k 10 300 python3 bench.py --scheme 0 --workload config5 --no-cpu-baseline > profiles/${tag}_bench_config5_scheme0.json 2>> $out/bench_scheme0.err
