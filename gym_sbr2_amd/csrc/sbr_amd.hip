@@ -1354,8 +1354,10 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     CREATE_TRY(hipEventCreate(&e->ev1));
     {
         const int lds_bytes = kLdsTableDoubles * (int)sizeof(double);      // 84 KiB of dynamic LDS: above the 64 KiB default
-        const void* fns[4] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
-                              reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>)};
+        const void* fns[8] = {reinterpret_cast<const void*>(&k_reset<float, false>), reinterpret_cast<const void*>(&k_reset<float, true>),
+                              reinterpret_cast<const void*>(&k_reset<double, false>), reinterpret_cast<const void*>(&k_reset<double, true>),
+                              reinterpret_cast<const void*>(&k_reset<float, false, 512>), reinterpret_cast<const void*>(&k_reset<float, true, 512>),
+                              reinterpret_cast<const void*>(&k_reset<double, false, 512>), reinterpret_cast<const void*>(&k_reset<double, true, 512>)};
         for (const void* fn : fns) CREATE_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         const void* cfns[4] = {reinterpret_cast<const void*>(&k_cycle_reset<float, false>), reinterpret_cast<const void*>(&k_cycle_reset<float, true>),
                                reinterpret_cast<const void*>(&k_cycle_reset<double, false>), reinterpret_cast<const void*>(&k_cycle_reset<double, true>)};
