@@ -101,6 +101,14 @@ def test_serial_bound_constants_and_larger_batches_are_hash_matched_committed_re
     lb = bench.larger_batches(h, d)
     assert list(lb) == ["131072"] and lb["131072"]["frac"] == 0.4 and lb["131072"]["us_per_launch"] == 20.0
     assert bench.larger_batches(flipped, d).keys() == {"262144"} and bench.larger_batches(None, d) is None
+    # ... and the kernel-trace summary of the same run, when the round took one, travels with the entry
+    with open(os.path.join(d, "r05_bench_config2_n131072_kernel_stats.csv"), "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+                '"void k_step<float, float, 256, false, 1, 2>(double*)",1000,16810598,16810.598,93.0,15000,40000,100.0\n'
+                '"void k_reset<float, false, 512>(SbrPar)",4,1800000,450000.0,6.0,440000,460000,10.0\n')
+    kt = bench.larger_batches(h, d)["131072"]
+    assert kt["kernel_trace_calls"] == 1000 and abs(kt["kernel_trace_us_per_launch"] - 16.810598) < 1e-9
+    assert abs(kt["frac_kernel_trace"] - 131072 * 513 / 16.810598e-6 / 8e12) < 1e-9 and kt["frac"] == 0.4
     # no literal of the old kind is left in bench.py
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"arithmetic_us": 6.3' not in src and "1.82" not in src
