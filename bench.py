@@ -9,7 +9,8 @@ CPU baseline.
 A "step" is one sbr_step() launch over this rank's batch: every env advances one control interval (two on the three
 phase-boundary calls of an episode).  Workloads (BASELINE.json `configs`):
     config2 (default)  65536 envs per GPU, stochastic influent (Philox normals drawn on the device), per-call random float32
-                       set-points already resident in HBM, per-step API, RK4 h = dt.  With N > 1 GPUs the envs are sharded by
+                       set-points already resident in HBM, per-step API, cfg.scheme = 1 (adaptive Butcher-5 per interval and
+                       env; `--scheme 0`: ten RK4 substeps, h = dt).  With N > 1 GPUs the envs are sharded by
                        global id through gym_sbr2_amd.ShardedSbrOS (the class the sharding tests cover); the one collective of
                        the path, an RCCL all-gather of the float32 episode returns, runs at every episode boundary (every 463
                        calls).  A timed region shorter than an episode (the driver's `--steps 20 --warmup 5`) contains no
@@ -29,8 +30,28 @@ Policies (`--policy`):
                        physical domain for the whole episode (`env_status.near_pole_frac_last_episode` = 0), so the timed
                        trajectories are ones on which parity with the reference is defined and asserted
                        (tests/test_gpu_parity.py::test_bench_workload_parity_at_65536_with_the_physical_policy).
-    uniform            u_DO ~ U[0, 8], u_EC ~ U[0, 15] on all eight scenarios (round 1's workload): over-aerates, drives
-                       ammonia negative in 86 % of the envs (the reference model has no guards); cost is data-independent.
+    uniform            u_DO ~ U[0, 8], u_EC ~ U[0, 15] on all eight scenarios (SURVEY.md 8d's synthetic inputs, round 1's workload):
+                       over-aerates, drives ammonia negative in 86 % of the envs (the reference model has no guards).  Under
+                       cfg.scheme = 1 the cost of a call depends on the state (step counts are chosen per env): the measured
+                       ratio to the physical policy is in profiles/r06_bench_config2_uniform.json / DESIGN.md section 5.
+    walk               the policy shape the reference itself defines (get_available_actions, gym_SBR_oneshot.py:440-459): from
+                       u_DO = 0, u_EC = 15 (:212-213) every call moves each set-point by one of {-0.1, 0, +0.1} / {-5, 0, +5},
+                       uniformly among the moves that stay inside [0, 8] x [0, 15]; scenarios 4..7.  A SECONDARY line (steadier
+                       set-points keep lanes out of the oxygen knee, so scheme 1 takes fewer steps): never the headline.
+Which calls are timed.  A region shorter than an episode (the driver's `--steps 20 --warmup 5`) is placed so that it straddles the
+first anoxic -> aerobic phase boundary with the episode's own mix of anoxic and aerobic calls (51 % anoxic): the episode is advanced
+untimed to call 36, five warm-up calls follow, and calls 41 .. 60 are timed - ten anoxic calls (two-step intervals), the
+phase-boundary call with its double step, nine aerobic ones (`config.timed_calls`, `config.anoxic_share_of_timed_calls`).  Until
+round 5 the region was calls 5 .. 24, all anoxic: the cheapest twenty calls of an episode.  Regions of an episode or more start at
+call W as before (they hold every kind of call, the terminal call and the reset).
+The large-batch leg.  With `--gpus 1`, workload config2 and no `--envs-per-gpu`, the run then times a SECOND handle of 262 144 envs
+(configs[3]'s total on one GPU, 84 MB of state; above 65 536 envs a launch has more wavefronts than the chip has SIMDs and runs the
+two-waves-per-SIMD build of k_step) with the same bracket, priming, window and K, and reports it as
+`roofline.larger_batches["262144"]` with `measured_in_this_run: true`: north_star's ">= 40 % of HBM roofline on one MI355X" measured
+inside this very command.  The headline fields stay configs[2]'s.  `--no-large-leg` skips it.
+`python bench.py --gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) starts the ranks itself: a child process
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py ...`
+(subprocess, started before anything in this process touches a GPU; never an exec), whose one JSON line and return code are relayed.
 Episodes end after 463 calls; the reset (influent draw + 252-substep fill phase) runs INSIDE the timed region and is
 not counted as steps.  Before the W warm-up steps the same workload runs untimed for PRIME_SECONDS of wall time: the GPU needs
 ~25 ms of sustained work to reach its steady clocks (measured with scripts/probes/clock_ramp.py: 20.95 us per launch in the
@@ -74,8 +95,50 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 MAX_CLOCK_GHZ = 2.4                    # the same guide, chip-level parameters
 SIMDS = 1024
 PRIME_SECONDS = 0.3                    # untimed: brings the GPU to steady clocks before warm-up and timing
-# phase schedule of an episode in calls (tests/golden/constants.npz): anoxic 46 intervals, aerobic 190, anoxic 171, aerobic 1
-ANOXIC_CALLS = [(0, 46), (235, 405)]   # calls whose interval doses carbon under a random NO3 set-point (boundary calls +-1)
+LARGE_LEG_ENVS = 262144                # the in-run large-batch leg: configs[3]'s total on ONE GPU (k_step's two-waves-per-SIMD build)
+
+
+def episode_schedule(cfg=None):
+    """Which kind of control interval every step() call of an episode runs: a list (one entry per call) of tuples of 0 (anoxic)
+    / 1 (aerobic), from the reference's own logic - four sequential tests on the running time t, which advances by t_delta per
+    interval in float64 (gym_SBR_oneshot.py:860, :896, :931, :963, :1122; the library's sbr_phase).  With the reference's
+    constants: 463 calls, calls 0..50 anoxic, call 51 anoxic + aerobic (double step), 52..274 aerobic, 275 aerobic + anoxic,
+    276..461 anoxic, 462 anoxic + aerobic = the done call.  `cfg` is anything with T_fill, T3_0, T3_end, T4_end, T5_end,
+    t_delta (default: the reference's values)."""
+    g = (lambda k, d: getattr(cfg, k, d)) if cfg is not None else (lambda k, d: d)
+    t = g("T_fill", 0.021); t_delta = g("t_delta", 0.002 / 24 * 10)
+    t30, t3e, t4e, t5e = g("T3_0", 0.06416666666666668), g("T3_end", 0.2516666666666667), g("T4_end", 0.4085000000000001), g("T5_end", 0.40933333333333344)
+    calls = []
+    while len(calls) < 100000:
+        kinds = []
+        if t < t30:
+            kinds.append(0); t = t + t_delta
+        if t30 <= t <= t3e:
+            kinds.append(1); t = t + t_delta
+        if t3e < t <= t4e:
+            kinds.append(0); t = t + t_delta
+        if t > t4e:
+            kinds.append(1); t = t + t_delta
+        calls.append(tuple(kinds))
+        if t >= t5e:
+            break
+    return calls
+
+
+def timed_window_start(steps, warmup, sched):
+    """First timed call (0-based index into the episode) of a K-step region after W warm-up calls.  A region of less than an
+    episode is centred on the first anoxic -> aerobic boundary so that its share of anoxic calls is the episode's; longer regions
+    start at call W (they contain whole episodes)."""
+    n = len(sched)
+    if steps >= n:
+        return warmup % n
+    anoxic = [1.0 if k[-1] == 0 else 0.0 for k in sched]
+    share = sum(anoxic) / n
+    boundary = next((c for c, k in enumerate(sched) if len(k) > 1), None)       # the first double-step call
+    if boundary is None:
+        return warmup % n
+    start = boundary - int(round(share * steps))
+    return min(max(start, warmup), n - steps)
 def reference_cpu():
     """The Python reference itself, timed by oracle/time_reference.py in the BUILD CONTAINER (the reference cannot travel to the
     GPU box) and committed as profiles/reference_cpu_timing.json: read here, never measured or imported by this file."""
@@ -90,7 +153,19 @@ def reference_cpu():
             "script": "oracle/time_reference.py"}
 
 
-def cpu_baseline(n_envs=16384, calls=463, physical=True, scheme=1):
+def walk_move(cur, pick, xp):
+    """One move of the reference's action model (get_available_actions, gym_SBR_oneshot.py:440-459): `cur` [n, 2] set-points,
+    `pick` [n, 2] integers in {0, 1, 2} choosing among the deltas (-0.1, 0, +0.1) / (-5, 0, +5); a move that would leave
+    [0, 8] x [0, 15] is not available there, so the set-point stays (the draw is then among the available moves with the
+    unavailable one's share going to `stay`).  xp = numpy or torch."""
+    delta = (pick - 1) * (xp.asarray([0.1, 5.0]) if xp.__name__ == "numpy" else xp.tensor([0.1, 5.0], device=cur.device, dtype=cur.dtype))
+    nxt = cur + delta
+    hi = xp.asarray([8.0, 15.0]) if xp.__name__ == "numpy" else xp.tensor([8.0, 15.0], device=cur.device, dtype=cur.dtype)
+    ok = (nxt >= 0) & (nxt <= hi)
+    return xp.where(ok, nxt, cur)
+
+
+def cpu_baseline(n_envs=16384, calls=463, policy="physical", scheme=1):
     """The CPU oracle (a C port of the same algorithm: the same integrator scheme, fp64, OpenMP over envs) timed on this box's
     host cores, on a bounded sample of the same workload.  Reported beside the GPU number; it is not the target.
     Its first pass also counts, per call of the episode, what the integrator did on this workload (the GPU does not report it):
@@ -101,11 +176,18 @@ def cpu_baseline(n_envs=16384, calls=463, physical=True, scheme=1):
     from gym_sbr2_amd.vec_env import load_influent_tables
     means, stds = load_influent_tables()
     cores = min(len(os.sched_getaffinity(0)), 16)
+    physical = policy != "uniform"
     scen = ((4 + np.arange(n_envs) % 4) if physical else (np.arange(n_envs) % 8)).astype(np.int32)
     b = O.OracleBatch(n_envs, O.default_params(scheme=scheme), nthreads=cores)
     infl = b.mix(means, stds, scen, b.normals(0))
     rs = np.random.RandomState(0)
-    acts = [np.column_stack([rs.uniform(0, 2.5 if physical else 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
+    if policy == "walk":
+        acts, cur = [], np.column_stack([np.zeros(n_envs), np.full(n_envs, 15.0)])
+        for _ in range(calls):
+            cur = walk_move(cur, rs.randint(0, 3, (n_envs, 2)), np)
+            acts.append(cur.astype(np.float32).astype(np.float64))
+    else:
+        acts = [np.column_stack([rs.uniform(0, 2.5 if physical else 8, n_envs), rs.uniform(0, 15, n_envs)]) for _ in range(calls)]
     best = 0.0
     per_call = {"dosing_wave_share": [], "steps_lane_mean": [], "steps_wave_mean": []}
     b.reset(infl)
@@ -321,19 +403,286 @@ def bench_cycle(args, torch, dist, world, rank, local_rank, dev, emit):
         emit(out)
 
 
-def main():
+class StepLeg:
+    """One handle of n_local envs of the per-step workload (or the fused rollout), with everything a timed region needs: the
+    resident action pool, the captured step graphs, episode bookkeeping and the event-timed launches.  The headline leg and the
+    in-run large-batch leg are two instances of this."""
+
+    def __init__(self, torch, dist, args, cfg, n_local, rank, world, dev_index, dist_up, fused=False, deterministic_influent=False):
+        from gym_sbr2_amd import ShardedSbrOS, _capi
+        self.torch, self.dist, self.args, self.capi = torch, dist, args, _capi
+        self.n_local, self.world, self.rank, self.dist_up, self.fused = n_local, world, rank, dist_up, fused
+        self.dev = torch.device("cuda", dev_index)
+        self.n_global = n_local * world
+        policy = args.policy
+        self.physical = policy != "uniform"
+        self.do_max = 2.5 if policy == "physical" else 8.0
+        # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK
+        self.sh = ShardedSbrOS(self.n_global, rank=rank, world=world, device=dev_index, out_dtype=torch.float32, config=cfg)
+        self.env, first = self.sh.env, self.sh.start
+        assert self.env.num_envs == n_local and self.env.device == self.dev, (self.env.num_envs, self.env.device, self.dev)
+        gid = torch.arange(first, first + n_local, device=self.dev)
+        self.scenario = ((4 + gid % 4) if self.physical else (gid % 8)).to(torch.int32)
+        self.rnd0 = torch.zeros(n_local, 48, dtype=torch.float64, device=self.dev) if deterministic_influent else None
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(1234 + rank)
+        if policy == "walk":           # history-dependent: one row per call of the episode, built once (untimed)
+            rows, cur = [], torch.tensor([0.0, 15.0], device=self.dev).repeat(n_local, 1)
+            for _ in range(CALLS_PER_EPISODE):
+                pick = torch.randint(0, 3, (n_local, 2), device=self.dev, generator=gen)
+                cur = walk_move(cur, pick, torch)
+                rows.append(cur.clone())
+            self.pool_rows = rows
+        else:
+            pool = torch.rand(64, n_local, 2, device=self.dev, generator=gen) * torch.tensor([self.do_max, 15.0], device=self.dev)
+            self.pool_rows = [pool[k] for k in range(64)]      # the [N, 2] views, made once: indexing a tensor costs the host ~2 us per call
+        self.n_rows = len(self.pool_rows)
+        self.state = {"episode": 0, "in_episode": 0, "returns": None}
+        self.seg_events, self.graphs = [], {}
+        self.gbufs = self.sh.gather_buffers(torch.float32)       # float64 row, float32 send, float32 [n_global] recv: allocated once
+        self.status_snap = torch.empty(n_local, dtype=torch.float64, device=self.dev)
+        self.acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "allgathers": 0, "call_ranges": []}
+        self.event_pool = []
+
+    # ---- the workload
+    def reset(self):
+        self.env.reset(seed=1000 + self.state["episode"], scenario=self.scenario, rnd=self.rnd0)
+        self.state["episode"] += 1
+        self.state["in_episode"] = 0
+
+    def end_of_episode(self):
+        # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync, no allocation):
+        # the per-env returns, collated over ranks by the one collective of the path (configs[3])
+        self.state["returns"] = self.sh.gather_episode_returns_into(self.gbufs)      # all_gather_into_tensor when a group is up
+        self.acct["allgathers"] += 1 if self.dist_up else 0
+        self.env.ctrl_row(self.capi.C_STATUS, out=self.status_snap)     # snapshot only; reduced after the timed region
+
+    # The step launches are issued as HIP-graph replays (chunks of <= 64 steps; sbr_step allocates nothing and synchronises
+    # nothing, so a run of steps is capturable - DESIGN.md section 2): one host call per chunk instead of one ctypes call per
+    # step.  With scheme 1 an anoxic call takes < 10 us on the GPU, and issuing 20 of them through Python took the host
+    # 5 .. 13 us per step depending on the box (round 5: a driver-style run came out host-bound at 14.2 us per step on a slow
+    # host, 11.1 on a fast one).  The captured launches are exactly the eager ones; --no-graphs issues them eagerly.
+    @staticmethod
+    def chunks(c0, m):
+        while m > 0:
+            r = c0 & 63
+            ln = min(m, 64 - r)
+            yield c0, ln
+            c0 += ln; m -= ln
+
+    def issue_steps(self, c0, m):
+        for c, ln in self.chunks(c0, m):
+            g = self.graphs.get((c % self.n_rows, ln))
+            if g is not None:
+                g.replay()
+            else:
+                for j in range(c, c + ln):
+                    self.env.step(self.pool_rows[j % self.n_rows])
+
+    def capture_for(self, schedule):
+        """Capture (untimed; nothing executes during capture) a graph for every chunk the given (call index, count) segments
+        will issue."""
+        if self.args.no_graphs or self.fused:
+            return
+        for c0, m in schedule:
+            for c, ln in self.chunks(c0, m):
+                key = (c % self.n_rows, ln)
+                if key not in self.graphs and ln > 1:
+                    self.graphs[key] = self.env.capture_steps([self.pool_rows[j % self.n_rows] for j in range(c, c + ln)])
+
+    def run(self, k_steps, record):
+        done = 0
+        st, acct = self.state, self.acct
+        while done < k_steps:
+            if st["in_episode"] == CALLS_PER_EPISODE:
+                ta = time.perf_counter()
+                self.end_of_episode()
+                tb = time.perf_counter()
+                self.reset()
+                if record:
+                    acct["end_of_episode_ms"] += (tb - ta) * 1e3
+                    acct["reset_issue_ms"] += (time.perf_counter() - tb) * 1e3
+            m = min(k_steps - done, CALLS_PER_EPISODE - st["in_episode"])
+            if record:
+                e0, e1 = self.event_pool.pop(), self.event_pool.pop()      # created before the timed region: no harness work in it
+                e0.record()
+            if self.fused:
+                self.env.rollout(m, policy_seed=77)
+            else:
+                self.issue_steps(st["in_episode"], m)
+            if record:
+                e1.record()
+                self.seg_events.append((e0, e1, m))
+                acct["call_ranges"].append((st["in_episode"], st["in_episode"] + m))
+            st["in_episode"] += m
+            done += m
+
+    def fence(self):
+        torch = self.torch
+        torch.cuda.synchronize(self.dev)
+        if self.dist_up:
+            self.dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def measure(self, steps, warmup, start_call):
+        """Priming, warm-up and the timed region of `steps` calls whose first is call `start_call` of an episode.  Returns a dict
+        of raw measurements (this rank's)."""
+        torch = self.torch
+        # untimed priming: one pass over everything an episode boundary touches (allocator growth, lazy loading of torch's
+        # kernels, RCCL's first collective), then W warm-up steps.  Nothing here is counted.
+        self.reset()
+        self.end_of_episode()
+        self.reset()
+        # HIP events for the device time of the step launches.  torch creates an event at its first record(), and the first
+        # timed record of a process costs 30-45 us on top (scripts/probes/sync_wait.py, profiles/r02_sync_wait.log): the warm-up
+        # steps go through the same recording code path and every event of the pool is recorded once, so that the timed region
+        # contains the workload only - with --steps 20 that harness cost was 12 % of the region.
+        self.event_pool = [torch.cuda.Event(enable_timing=True)
+                           for _ in range(2 * (steps // CALLS_PER_EPISODE + warmup // CALLS_PER_EPISODE + 6))]
+        for ev in self.event_pool:
+            ev.record()
+        # every chunk the run will issue: whole episodes (priming, long regions), the untimed advance to the window, the warm-up's
+        # W - 1 and 1 steps, the K timed steps (all modulo the episode length)
+        lead = (start_call - warmup) % CALLS_PER_EPISODE
+        sched, c = [(0, CALLS_PER_EPISODE)], 0
+        for m_ in (lead, max(warmup - 1, 0), min(warmup, 1), steps):
+            left = m_
+            while left > 0:
+                take = min(left, CALLS_PER_EPISODE - c)
+                sched.append((c, take))
+                c = (c + take) % CALLS_PER_EPISODE
+                left -= take
+        self.capture_for(sched)
+        # The collector runs HERE, before the clocks are primed, and stays off until the timed region is over: a collection of a
+        # torch process takes tens of milliseconds of host time during which the GPU idles and drops out of its steady clocks
+        # (round 3, scripts/probes/rollout_sustained.py: the first 25 ms after such a gap run up to 24 % slower) - placed between
+        # priming and timing, as it was, it undid the priming for every region shorter than ~30 ms.
+        gc.collect(); gc.disable()
+        if self.dist_up:                            # the first barrier of a process group is slow (lazy connection set-up): not
+            self.fence()                            # between priming and timing either
+        t_prime = time.perf_counter()
+        while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
+            self.run(CALLS_PER_EPISODE, record=False)
+            torch.cuda.synchronize(self.dev)
+        t_primed = time.perf_counter()
+        if self.state["in_episode"] == CALLS_PER_EPISODE:         # the advance, warm-up and timing start at the first call of an episode
+            self.end_of_episode()
+            self.reset()
+        self.run(lead, record=False)                              # untimed: up to the call the warm-up starts at
+        self.run(max(warmup - 1, 0), record=True)
+        # opening bracket: synchronise, barrier, the last warm-up step, synchronise (see the module docstring)
+        torch.cuda.synchronize(self.dev)
+        if self.dist_up:
+            self.dist.barrier()
+        self.run(min(warmup, 1), record=True)
+        torch.cuda.synchronize(self.dev)
+        self.seg_events.clear()
+        self.acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, allgathers=0, call_ranges=[])
+        episodes_before = self.state["episode"]
+        t0 = time.perf_counter()
+        gap_ms = (t0 - t_primed) * 1e3              # (diagnostic) host time between the end of clock priming and the timed region
+        self.run(steps, record=True)
+        if self.dist_up and self.acct["allgathers"] == 0:     # no episode boundary fell into the K steps: the collective of the path
+            self.end_of_episode()                             # still runs once inside the timed region of an N > 1 run (returns so far)
+        t_issued = time.perf_counter()              # (diagnostic) the host has issued every launch of the region
+        torch.cuda.synchronize(self.dev)            # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
+        elapsed = time.perf_counter() - t0          # - the MAX over ranks (caller) is what makes it the time of the slowest rank, and
+        self.fence()                                # a collective's own latency is not part of the K steps
+        gc.enable()
+        dev_ms = sum(a.elapsed_time(b) for a, b, _ in self.seg_events)
+        launches = sum(m for _, _, m in self.seg_events) if not self.fused else len(self.seg_events)
+        return {"elapsed": elapsed, "dev_ms": dev_ms, "launches": launches, "segments": len(self.seg_events),
+                "host_issue_ms": (t_issued - t0) * 1e3, "gap_ms": gap_ms, "resets_timed": self.state["episode"] - episodes_before,
+                "timed_calls": [c for lo, hi in self.acct["call_ranges"] for c in range(lo, hi)]}
+
+    def device_plan_counts(self, calls):
+        """What cfg.scheme = 1 did on THIS leg's envs, counted on the device (round 6): one more episode with the same seeds,
+        actions and call order as the timed ones (untimed, eager), reading the plan row (SBR_C_PLAN: step count and slaved bit of
+        each env's last interval) after every call of `calls`.  Returns per-env and per-wavefront means over those calls."""
+        torch, capi = self.torch, self.capi
+        if not hasattr(capi, "C_PLAN") or not calls:
+            return None
+        want = set(calls)
+        row = torch.empty(self.n_local, dtype=torch.float64, device=self.dev)
+        self.reset()
+        lane_sum = wave_sum = slaved_sum = 0.0
+        dose_sum = 0.0
+        full = self.n_local - self.n_local % 64
+        ec = torch.empty(self.n_local, dtype=torch.float64, device=self.dev)
+        for c in range(max(want) + 1):
+            self.env.step(self.pool_rows[c % self.n_rows])
+            if c in want:
+                self.env.ctrl_row(capi.C_PLAN, out=row)
+                p = row.to(torch.int64)
+                n = (p & 127).to(torch.float64)
+                lane_sum += float(n.mean().item())
+                wave_sum += float(n[:full].view(-1, 64).max(dim=1).values.mean().item())
+                slaved_sum += float(((p & 128) != 0).double().mean().item())
+                self.env.ctrl_row(capi.C_EC_LAST, out=ec)
+                dose_sum += float((ec[:full].view(-1, 64) != 0).any(dim=1).double().mean().item())
+        self.state["in_episode"] = max(want) + 1
+        k = float(len(want))
+        return {"per_env_mean": lane_sum / k, "per_wavefront_mean": wave_sum / k, "slaved_share": slaved_sum / k,
+                "dosing_wave_call_share": dose_sum / k, "calls_counted": len(want), "envs_counted": self.n_local,
+                "source": "device: SBR_C_PLAN / SBR_C_EC_LAST read after each of the timed calls in a replay of the same episode (untimed)"}
+
+    def close(self):
+        self.env.close()
+
+
+def step_kernel_label(env, scheme, fused):
+    """The kernel instantiation the library launches for this handle, from the library's own thresholds (sbr_query, round 6; until
+    then bench.py repeated them as literals)."""
+    from gym_sbr2_amd import _capi
+    q = getattr(env, "query", None)
+    if q is None:
+        return None
+    if fused:
+        return "k_rollout<false,%d,%d>" % (scheme, q(_capi.Q_ROLLOUT_WAVES))
+    return "k_step<float,float,%d,false,%d,%d>" % (q(_capi.Q_STEP_BLOCK), scheme, q(_capi.Q_STEP_WAVES))
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks as a CHILD process group through
+    torch.distributed.run and relay rank 0's JSON line and the return code.  Runs before this process has imported torch or
+    touched a GPU; a subprocess, never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, SBR_BENCH_SELF_LAUNCHED="1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return p.returncode if (p.returncode != 0 or lines) else 1
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1852)       # four episodes
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config5", "cycle"])
     ap.add_argument("--envs-per-gpu", type=int, default=None)
-    ap.add_argument("--policy", default="physical", choices=["physical", "uniform"])
+    ap.add_argument("--policy", default="physical", choices=["physical", "uniform", "walk"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-leg", action="store_true", help="skip the in-run 262144-env leg (roofline.larger_batches['262144'])")
     ap.add_argument("--no-graphs", action="store_true", help="issue every step launch eagerly (one ctypes call per step)")
     ap.add_argument("--scheme", type=int, default=None, choices=[0, 1],
                     help="cfg.scheme: 1 (library default) adaptive Butcher-5 per interval, 0 ten RK4 substeps (rounds 1-4)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.policy == "walk" and args.workload in ("config5", "cycle"):
+        raise SystemExit("--policy walk is a per-step policy: the fused rollout draws its actions on the device, the per-cycle env takes three set-points per cycle")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
 
     # Native libraries print to fd 1 (RCCL writes a five-line version banner when a communicator is created); the contract is
     # ONE JSON line on stdout, so fd 1 points at stderr until the result is printed.
@@ -348,13 +697,13 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from gym_sbr2_amd import ShardedSbrOS, _capi
+    from gym_sbr2_amd import _capi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     # One process per GPU: rank r drives device LOCAL_RANK.  SBR_BENCH_BACKEND=gloo is a REHEARSAL mode for a box with fewer
@@ -382,175 +731,28 @@ def main():
         return bench_cycle(args, torch, dist, world, rank, dev_index, dev, emit)
     n_local = args.envs_per_gpu or (4096 if args.workload == "config1" else 65536)
     n_global = n_local * world
-    physical = args.policy == "physical"
-    do_max = 2.5 if physical else 8.0
+    physical = args.policy != "uniform"
+    do_max = 2.5 if args.policy == "physical" else 8.0
     cfg = _capi.default_config()
     if args.scheme is not None:
         cfg.scheme = args.scheme
     elif args.workload == "config1":
         cfg.scheme = 0                    # BASELINE.json words configs[1] as "fixed-step RK4"; --scheme 1 runs the default scheme on it
     scheme = int(cfg.scheme)
-    cfg.act_DO_max = do_max               # what the fused rollout's on-device policy draws from (and clips to)
-    # the class the multi-GPU tests cover: contiguous shards by global env id, device = LOCAL_RANK
-    sh = ShardedSbrOS(n_global, rank=rank, world=world, device=dev_index, out_dtype=torch.float32, config=cfg)
-    env, first = sh.env, sh.start
-    assert env.num_envs == n_local and env.device == dev, (env.num_envs, env.device, dev)
-    gid = torch.arange(first, first + n_local, device=dev)
-    scenario = ((4 + gid % 4) if physical else (gid % 8)).to(torch.int32)
-    rnd0 = torch.zeros(n_local, 48, dtype=torch.float64, device=dev) if args.workload == "config1" else None
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    pool = torch.rand(64, n_local, 2, device=dev, generator=gen) * torch.tensor([do_max, 15.0], device=dev)   # resident actions
-    pool_rows = [pool[k] for k in range(64)]       # the 64 [N, 2] views, made once: indexing a tensor costs the host ~2 us per call
+    cfg.act_DO_max = do_max if args.policy != "walk" else 8.0      # what the fused rollout's on-device policy draws from (and clips to)
     fused = args.workload == "config5"
-    state = {"episode": 0, "in_episode": 0, "returns": None}
-    seg_events = []
-
-    def reset():
-        env.reset(seed=1000 + state["episode"], scenario=scenario, rnd=rnd0)
-        state["episode"] += 1
-        state["in_episode"] = 0
-
-    gbufs = sh.gather_buffers(torch.float32)          # float64 row, float32 send, float32 [n_global] recv: allocated once, here
-    status_snap = torch.empty(n_local, dtype=torch.float64, device=dev)
     dist_up = world > 1 or force_dist
-    acct = {"end_of_episode_ms": 0.0, "reset_issue_ms": 0.0, "anoxic_calls": 0, "allgathers": 0, "call_ranges": []}
-
-    def end_of_episode():
-        # what the workload needs at an episode boundary, all asynchronous on the launch stream (no host sync, no allocation):
-        # the per-env returns, collated over ranks by the one collective of the path (configs[3])
-        state["returns"] = sh.gather_episode_returns_into(gbufs)      # all_gather_into_tensor when a group is up
-        acct["allgathers"] += 1 if dist_up else 0
-        env.ctrl_row(_capi.C_STATUS, out=status_snap)     # snapshot only; reduced after the timed region
-
-    # The step launches are issued as HIP-graph replays (chunks of <= 64 steps; sbr_step allocates nothing and synchronises
-    # nothing, so a run of steps is capturable - DESIGN.md section 2): one host call per chunk instead of one ctypes call per
-    # step.  With scheme 1 an anoxic call takes < 10 us on the GPU, and issuing 20 of them through Python took the host
-    # 5 .. 13 us per step depending on the box (round 5: a driver-style run came out host-bound at 14.2 us per step on a slow
-    # host, 11.1 on a fast one).  The captured launches are exactly the eager ones; --no-graphs issues them eagerly.
-    graphs = {}
-
-    def chunks(c0, m):
-        while m > 0:
-            r = c0 & 63
-            ln = min(m, 64 - r)
-            yield r, ln
-            c0 += ln; m -= ln
-
-    def issue_steps(c0, m):
-        for r, ln in chunks(c0, m):
-            g = graphs.get((r, ln))
-            if g is not None:
-                g.replay()
-            else:
-                for j in range(r, r + ln):
-                    env.step(pool_rows[j])
-
-    def capture_for(schedule):
-        """Capture (untimed; nothing executes during capture) a graph for every chunk the given (call index, count) segments
-        will issue."""
-        if args.no_graphs or fused:
-            return
-        for c0, m in schedule:
-            for r, ln in chunks(c0, m):
-                if (r, ln) not in graphs and ln > 1:
-                    graphs[(r, ln)] = env.capture_steps([pool_rows[j] for j in range(r, r + ln)])
-
-    def run(k_steps, record):
-        done = 0
-        while done < k_steps:
-            if state["in_episode"] == CALLS_PER_EPISODE:
-                ta = time.perf_counter()
-                end_of_episode()
-                tb = time.perf_counter()
-                reset()
-                if record:
-                    acct["end_of_episode_ms"] += (tb - ta) * 1e3
-                    acct["reset_issue_ms"] += (time.perf_counter() - tb) * 1e3
-            m = min(k_steps - done, CALLS_PER_EPISODE - state["in_episode"])
-            if record:
-                e0, e1 = event_pool.pop(), event_pool.pop()      # created before the timed region: no harness work in it
-                e0.record()
-            if fused:
-                env.rollout(m, policy_seed=77)
-            else:
-                issue_steps(state["in_episode"], m)
-            if record:
-                e1.record()
-                seg_events.append((e0, e1, m))
-                c0 = state["in_episode"]
-                acct["call_ranges"].append((c0, c0 + m))
-                acct["anoxic_calls"] += sum(max(0, min(c0 + m, hi) - max(c0, lo)) for lo, hi in ANOXIC_CALLS)
-            state["in_episode"] += m
-            done += m
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # untimed priming: one pass over everything an episode boundary touches (allocator growth, lazy loading of torch's
-    # kernels, RCCL's first collective), then W warm-up steps.  Nothing here is counted.
-    reset()
-    end_of_episode()
-    reset()
-    # HIP events for the device time of the step launches.  torch creates an event at its first record(), and the first
-    # timed record of a process costs 30-45 us on top (scripts/probes/sync_wait.py, profiles/r02_sync_wait.log): the warm-up
-    # steps go through the same recording code path and every event of the pool is recorded once, so that the timed region
-    # contains the workload only - with --steps 20 that harness cost was 12 % of the region.
-    event_pool = [torch.cuda.Event(enable_timing=True)
-                  for _ in range(2 * (args.steps // CALLS_PER_EPISODE + args.warmup // CALLS_PER_EPISODE + 6))]
-    for ev in event_pool:
-        ev.record()
-    # The collector runs HERE, before the clocks are primed, and stays off until the timed region is over: a collection of a
-    # torch process takes tens of milliseconds of host time during which the GPU idles and drops out of its steady clocks
-    # (round 3, scripts/probes/rollout_sustained.py: the first 25 ms after such a gap run up to 24 % slower) - placed between
-    # priming and timing, as it was, it undid the priming for every region shorter than ~30 ms.
-    # every chunk the run will issue: whole episodes (priming, long regions), the warm-up's W - 1 and 1 steps from call 0, the K
-    # timed steps from call W (all modulo the episode length)
-    sched, c = [(0, CALLS_PER_EPISODE)], 0
-    for m_ in (max(args.warmup - 1, 0), min(args.warmup, 1), args.steps):
-        left = m_
-        while left > 0:
-            take = min(left, CALLS_PER_EPISODE - c)
-            sched.append((c, take))
-            c = (c + take) % CALLS_PER_EPISODE
-            left -= take
-    capture_for(sched)
-    gc.collect(); gc.disable()
-    if dist_up:                                 # the first barrier of a process group is slow (lazy connection set-up): not
-        fence()                                 # between priming and timing either
-    t_prime = time.perf_counter()
-    while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
-        run(CALLS_PER_EPISODE, record=False)
-        torch.cuda.synchronize(dev)
-    t_primed = time.perf_counter()
-    if state["in_episode"] == CALLS_PER_EPISODE:              # warm-up and timing start at the first call of an episode
-        end_of_episode()
-        reset()
-    run(max(args.warmup - 1, 0), record=True)
-    # opening bracket: synchronise, barrier, the last warm-up step, synchronise (see the module docstring)
-    torch.cuda.synchronize(dev)
-    if world > 1 or force_dist:
-        dist.barrier()
-    run(min(args.warmup, 1), record=True)
-    torch.cuda.synchronize(dev)
-    seg_events.clear()
-    acct.update(end_of_episode_ms=0.0, reset_issue_ms=0.0, anoxic_calls=0, allgathers=0, call_ranges=[])
-    episodes_before = state["episode"]
-    t0 = time.perf_counter()
-    gap_ms = (t0 - t_primed) * 1e3              # (diagnostic) host time between the end of clock priming and the timed region
-    run(args.steps, record=True)
-    if dist_up and acct["allgathers"] == 0:     # no episode boundary fell into the K steps: the collective of the path still
-        end_of_episode()                        # runs once inside the timed region of an N > 1 run (returns so far)
-    t_issued = time.perf_counter()              # (diagnostic) the host has issued every launch of the region
-    torch.cuda.synchronize(dev)                 # closing bracket: synchronise, read the clock, then the barrier (+ synchronise)
-    elapsed = time.perf_counter() - t0          # - the MAX over ranks below is what makes it the time of the slowest rank, and
-    fence()                                     # a collective's own latency is not part of the K steps
-    gc.enable()
+    sched = episode_schedule(cfg)
+    assert len(sched) == CALLS_PER_EPISODE, len(sched)
+    anoxic_of = [1.0 if k[-1] == 0 else 0.0 for k in sched]
+    start_call = timed_window_start(args.steps, args.warmup, sched) if not fused else args.warmup % CALLS_PER_EPISODE
+    leg = StepLeg(torch, dist, args, cfg, n_local, rank, world, dev_index, dist_up, fused=fused,
+                  deterministic_influent=args.workload == "config1")
+    env = leg.env
+    m = leg.measure(args.steps, args.warmup, start_call)
+    elapsed = m["elapsed"]
     rank_elapsed, rank_devices = [elapsed], ["cuda:%d %s" % (dev_index, torch.cuda.get_device_name(dev))]
-    if world > 1 or force_dist:
+    if dist_up:
         # one small all-gather AFTER the timed region: every rank's own time and device, so that the line says whether RCCL saw
         # N ranks on N devices and how skewed they were (VERDICT r3 item 8); `value` uses the MAX
         ws = dist.get_world_size()
@@ -564,19 +766,48 @@ def main():
         rank_devices = ["cuda:%d %s" % (int(allr[r, 1]), names[r]) for r in range(ws)]
         elapsed = max(rank_elapsed)
 
-    resets_timed = state["episode"] - episodes_before
+    resets_timed = m["resets_timed"]
     # dominant kernel: device time of the step launches of the timed region, from events on the launch stream
-    dev_ms = sum(a.elapsed_time(b) for a, b, _ in seg_events)
-    launches = sum(m for _, _, m in seg_events) if not fused else len(seg_events)
+    dev_ms, launches = m["dev_ms"], m["launches"]
     per_launch_s = dev_ms * 1e-3 / max(launches, 1)
-    calls_per_launch = 1 if not fused else args.steps / max(len(seg_events), 1)
+    calls_per_launch = 1 if not fused else args.steps / max(m["segments"], 1)
     achieved = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP / per_launch_s / 1e9
+    timed_calls = m["timed_calls"]
+    frac_anoxic = (sum(anoxic_of[c] for c in timed_calls) / len(timed_calls)) if timed_calls else None
+    lib_hash = loaded_library_hash()
+
+    # ---- the in-run large-batch leg: 262 144 envs on this one GPU, the same workload, bracket and K
+    large = None
+    if (world == 1 and not dist_up and args.workload == "config2" and args.envs_per_gpu is None and not args.no_large_leg
+            and rank == 0):
+        lleg = StepLeg(torch, dist, args, cfg, LARGE_LEG_ENVS, 0, 1, dev_index, False)
+        lm = lleg.measure(args.steps, args.warmup, start_call)
+        l_launch_s = lm["dev_ms"] * 1e-3 / max(lm["launches"], 1)
+        l_step_s = lm["elapsed"] / args.steps
+        l_bytes = LARGE_LEG_ENVS * ALGO_BYTES_PER_ENV_STEP
+        l_counts = lleg.device_plan_counts(lm["timed_calls"][:CALLS_PER_EPISODE]) if scheme == 1 else None
+        large = {"measured_in_this_run": True, "envs_per_launch": LARGE_LEG_ENVS, "steps": args.steps, "warmup": args.warmup,
+                 "ms_per_step": l_step_s * 1e3, "env_steps_per_s": LARGE_LEG_ENVS * args.steps / lm["elapsed"],
+                 "frac_wall": l_bytes / l_step_s / 1e9 / HBM_PEAK_GBPS, "frac": l_bytes / l_step_s / 1e9 / HBM_PEAK_GBPS,
+                 "avg_launch_us": l_launch_s * 1e6, "frac_timed_launches": l_bytes / l_launch_s / 1e9 / HBM_PEAK_GBPS,
+                 "launches_timed": lm["launches"], "resets_in_timed_region": lm["resets_timed"],
+                 "timed_calls": [lm["timed_calls"][0], lm["timed_calls"][-1] + 1] if len(lm["timed_calls"]) <= CALLS_PER_EPISODE else "whole episodes",
+                 "anoxic_share_of_timed_calls": sum(anoxic_of[c] for c in lm["timed_calls"]) / max(len(lm["timed_calls"]), 1),
+                 "kernel": step_kernel_label(lleg.env, scheme, False), "b5_steps_per_interval": l_counts,
+                 "algorithmic_bytes_per_launch": l_bytes,
+                 "note": "a second handle of 262144 envs (configs[3]'s total on ONE GPU) timed in this very run with the headline's "
+                         "bracket, priming, window and K; frac = frac_wall = 513 B x 262144 / ms_per_step / 8 TB/s (resets and episode "
+                         "boundaries inside when K spans them)"}
+        lleg.close()
+        del lleg
+        torch.cuda.empty_cache()
+
     # HBM bytes per launch and VALU instructions per wave from the PMC counters: collected offline with rocprofv3 --pmc
     # (scripts/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE / SQ passes, gfx950 fetch correction calibrated in the same
     # run) and committed under profiles/.  They are a COMMITTED CONSTANT, not a measurement of this run: attached only when the
     # profile was taken on the very library that is being timed (content hash of sources + flags), for the profiled batch size
     traffic, valu_per_wave = None, None
-    rec, traffic_note = pmc_record(loaded_library_hash())
+    rec, traffic_note = pmc_record(lib_hash)
     if rec and n_local != rec.get("envs_per_launch", 65536):
         rec, traffic_note = None, "the committed PMC profile is of %d envs per launch, this run has %d" % (rec.get("envs_per_launch", 65536), n_local)
     episode = None          # whole-episode launch time of the committed kernel trace of THIS library (hash-matched like traffic)
@@ -587,6 +818,8 @@ def main():
             rec_scheme = 1
         if rec_scheme != scheme:
             rec, traffic_note = None, "the committed PMC profile is of cfg.scheme = %d, this run has %d" % (rec_scheme, scheme)
+    if rec and rec.get("policy", "physical") != args.policy:
+        rec, traffic_note = None, "the committed PMC profile is of --policy %s, this run has %s" % (rec.get("policy", "physical"), args.policy)
     if rec and not fused and args.workload == "config2":
         traffic = rec["hbm_bytes_per_launch"]
         valu_per_wave = rec.get("valu_insts_per_wave")
@@ -602,34 +835,42 @@ def main():
                         "moved)" % (rr["calls_per_launch"], rec["_file"], rr["hbm_bytes_per_env_step"]))
     elif rec:
         traffic_note = "the committed PMC profile covers config2 and config5 only"
-    # The CPU baseline (rank 0 of a 1-GPU run) is taken here, after the timed region, because its first pass also counts what the
-    # integrator did on this workload call by call (the GPU does not report it): which wavefronts dosed, how many steps scheme 1
-    # took.  Those statistics are of the oracle's sample of the same workload (other random draws), not of the timed envs.
-    cpu = cpu_baseline(physical=physical, scheme=scheme) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    timed_calls = [c for lo, hi in acct["call_ranges"] for c in range(lo, hi)]
+    # What cfg.scheme = 1 did on the timed envs, counted ON THE DEVICE (round 6; until then: the CPU oracle's sample): a replay of
+    # the timed calls of one episode with the plan row read after every call.  After the timed region, untimed.
+    counts = None
+    if scheme == 1 and not fused and rank == 0:
+        counts = leg.device_plan_counts(sorted(set(timed_calls))[:CALLS_PER_EPISODE])
+    # The CPU baseline (rank 0 of a 1-GPU run), after the timed region.  Its first pass also counts what the integrator did on
+    # ITS sample of the workload (other random draws): kept as a cross-check of the device's count.
+    cpu = cpu_baseline(policy=args.policy, scheme=scheme) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     def over_timed_calls(key):
         v = cpu["per_call"].get(key) if cpu else None
         return (sum(v[c] for c in timed_calls) / len(timed_calls)) if (v and timed_calls) else None
-    frac_anoxic = acct["anoxic_calls"] / max(args.steps, 1)
-    dosing_share = over_timed_calls("dosing_wave_share")
+    dosing_share = counts["dosing_wave_call_share"] if counts else over_timed_calls("dosing_wave_share")
     waves = (n_local + 63) // 64
     if scheme == 1:
         # scheme 1: the work per interval is decided per env (1, 2 or 4 Butcher-5 steps of 767 FLOP; with dosing 865); a
         # wavefront executes its slowest lane's count with the other lanes masked.  `achieved` counts the USEFUL work (the mean
         # count per env at the closed-reactor figure: a lower bound), `executed_flop_per_env_step` what the wavefronts issued.
-        steps_lane, steps_wave = over_timed_calls("steps_lane_mean"), over_timed_calls("steps_wave_mean")
+        steps_lane = counts["per_env_mean"] if counts else over_timed_calls("steps_lane_mean")
+        steps_wave = counts["per_wavefront_mean"] if counts else over_timed_calls("steps_wave_mean")
         flop_per_step = steps_lane * FP64_FLOP_PER_B5_STEP["plain"] if steps_lane else None
         tflops = n_local * calls_per_launch * flop_per_step / per_launch_s / 1e12 if flop_per_step else None
         fp64 = {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / FP64_VECTOR_PEAK_TFLOPS if tflops else None, "flop_per_env_step": flop_per_step,
                 "executed_flop_per_env_step": steps_wave * FP64_FLOP_PER_B5_STEP["plain"] if steps_wave else None,
                 "b5_steps_per_interval": {"per_env_mean": steps_lane, "per_wavefront_mean": steps_wave,
+                                          "slaved_share": counts["slaved_share"] if counts else None,
+                                          "source": counts["source"] if counts else ("CPU oracle's sample of the same workload (other "
+                                                                                     "random draws), same calls" if cpu else None),
+                                          "cpu_oracle_sample": {"per_env_mean": over_timed_calls("steps_lane_mean"),
+                                                                "per_wavefront_mean": over_timed_calls("steps_wave_mean")} if cpu else None,
                                           "flop_per_step": FP64_FLOP_PER_B5_STEP, "rk4_equivalent_flop": SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]},
                 "anoxic_share_of_timed_calls": frac_anoxic,
-                "note": "cfg.scheme = 1: Butcher-5 step loops only, counted in the ISA (FMA = 2), step counts from the CPU oracle's "
-                        "sample of the same workload over the same calls of the episode (null with --no-cpu-baseline); scheme 0 "
-                        "spent 4300 FLOP per env-step on the same intervals"}
+                "note": "cfg.scheme = 1: Butcher-5 step loops only, counted in the ISA (FMA = 2); the step counts are the DEVICE's own "
+                        "(the plan row of the timed envs, read after each timed call in an untimed replay of the same episode); "
+                        "scheme 0 spent 4300 FLOP per env-step on the same intervals"}
     else:
         # scheme 0: the RK4 substep loops only, ALL counted at the closed-reactor loop's 426 FLOP per substep - a lower bound.  A
         # wave with at least one lane dosing carbon runs the dosing loop instead (464 FLOP per substep); how many do is a property
@@ -665,9 +906,7 @@ def main():
     # ---- roofline of the dominant kernel.  Three figures exist for the per-step path; `frac` is the CONSERVATIVE one (VERDICT r4
     # item 2): the whole-episode average of the committed rocprofv3 --kernel-trace --stats run of THIS library (hash-matched)
     # when there is one, and never above what this run's own wall clock allows (513 B x N / ms_per_step).
-    #   frac_timed_launches  513 B x N / mean device time of the launches this run timed (HIP events on the launch stream); with the
-    #                        driver's --steps 20 --warmup 5 those are calls 5..24 of an episode: anoxic, two-step intervals, no
-    #                        terminal call, no reset - the most flattering of the three
+    #   frac_timed_launches  513 B x N / mean device time of the launches this run timed (HIP events on the launch stream)
     #   frac_wall            513 B x N / (wall time of the K steps / K): includes resets, episode boundaries and host gaps
     #   frac_episode         513 B x N / AVERAGE duration of every k_step launch of the committed kernel trace of whole episodes
     algo_bytes = n_local * calls_per_launch * ALGO_BYTES_PER_ENV_STEP
@@ -675,21 +914,31 @@ def main():
     frac_wall = n_local * ALGO_BYTES_PER_ENV_STEP / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS      # a "step" = one call per env
     frac_episode = (n_local * ALGO_BYTES_PER_ENV_STEP / (episode["average_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS) if episode else None
     frac = min(frac_episode, frac_wall) if frac_episode is not None else frac_wall
-    lib_hash = loaded_library_hash()
     sb = serial_bound_record(lib_hash) if (not fused and n_local == 65536 and traffic) else None
     serial_bound = None
     if sb:
         mem_us = traffic / (HBM_PEAK_GBPS * 1e3)
         arith = sb["arithmetic_us"]
-        arith_mean = (217 * arith["anoxic"] + 246 * arith["aerobic"]) / 463.0       # 217 anoxic and 246 aerobic calls per episode
+        n_anoxic = int(sum(anoxic_of))
+        arith_mean = (n_anoxic * arith["anoxic"] + (CALLS_PER_EPISODE - n_anoxic) * arith["aerobic"]) / float(CALLS_PER_EPISODE)
         total = mem_us + arith_mean + sb["dependent_launch_floor_us"]
         serial_bound = {"memory_us": mem_us, "arithmetic_us": arith, "arithmetic_us_episode_mean": arith_mean,
+                        "anoxic_calls_per_episode": n_anoxic, "aerobic_calls_per_episode": CALLS_PER_EPISODE - n_anoxic,
                         "dependent_launch_floor_us": sb["dependent_launch_floor_us"], "sum_us": total,
                         "frac_at_bound": n_local * ALGO_BYTES_PER_ENV_STEP / (total * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                         "note": "what three measured numbers add up to when nothing overlaps (one wave per SIMD): memory_us from `traffic` "
                                 "of this library at the roofline's own rate; arithmetic (PIDs + integration, per-wave median of the stamp "
                                 "build) and the period of an empty dependent launch are committed measurements of this library (%s)"
                                 % sb["_file"]}
+    lb = None
+    if world == 1 and args.envs_per_gpu is None and args.workload == "config2":
+        lb = {}
+        for k_, v_ in (larger_batches(lib_hash) or {}).items():        # committed constants of this library, labelled as such
+            v_ = dict(v_, measured_in_this_run=False, committed_constant=True)
+            lb[k_ if (k_ != str(LARGE_LEG_ENVS) or large is None) else k_ + "_committed_record"] = v_
+        if large is not None:
+            lb[str(LARGE_LEG_ENVS)] = large
+        lb = lb or None
     roofline = {"bound": "hbm", "achieved": frac * HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac,
                 "frac_is": ("frac_episode" if (frac_episode is not None and frac_episode <= frac_wall) else "frac_wall"),
                 "frac_timed_launches": frac_timed, "frac_wall": frac_wall, "frac_episode": frac_episode,
@@ -700,11 +949,10 @@ def main():
                 "frac_episode_source": ("%s: %d k_step launches, average %.0f ns (committed constant, measured on this library)"
                                         % (episode["file"], episode["calls"], episode["average_ns"])) if episode else
                                        "no committed kernel trace of this library and batch size",
-                "larger_batches": (larger_batches(lib_hash) if (world == 1 and args.envs_per_gpu is None and args.workload == "config2")
-                                   else None),
-                "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": (t_issued - t0) * 1e3,
-                                    "host_in_end_of_episode": acct["end_of_episode_ms"],
-                                    "host_in_reset_issue": acct["reset_issue_ms"], "since_clock_priming": gap_ms},
+                "larger_batches": lb,
+                "timed_region_ms": {"wall": elapsed * 1e3, "step_kernels_device": dev_ms, "host_issue": m["host_issue_ms"],
+                                    "host_in_end_of_episode": leg.acct["end_of_episode_ms"],
+                                    "host_in_reset_issue": leg.acct["reset_issue_ms"], "since_clock_priming": m["gap_ms"]},
                 "fp64_valu": fp64, "serial_bound": serial_bound,
                 "headline": "fp64_valu" if fused else "hbm",
                 "note": ("FUSED kernel: plant and controllers stay in registers for the whole launch, so `achieved`/`frac` are the "
@@ -713,7 +961,8 @@ def main():
                          "78.6 TFLOP/s vector peak)") if fused else
                         ("the prescribed roofline is HBM (513 algorithmic bytes per env-step, SURVEY.md 8d); the kernel's actual "
                          "bound is float64 VALU issue plus the kernel boundary (DESIGN.md section 5), reported in fp64_valu")}
-    st_bits = status_snap.to(torch.int64)
+    st_bits = leg.status_snap.to(torch.int64)
+    few = len(timed_calls) <= CALLS_PER_EPISODE
     out = {
         "metric": "env-steps/sec (batched)",
         "value": n_global * args.steps / elapsed,
@@ -725,6 +974,12 @@ def main():
         "config": {"workload": workload,
                    "envs_per_gpu": n_local, "envs_total": n_global, "calls_per_episode": CALLS_PER_EPISODE,
                    "resets_in_timed_region": resets_timed, "clock_priming_s": PRIME_SECONDS,
+                   "timed_calls": ([timed_calls[0], timed_calls[-1] + 1] if (few and timed_calls) else
+                                   "whole episodes: %d calls from call %d on" % (len(timed_calls), timed_calls[0] if timed_calls else 0)),
+                   "timed_window": ("calls [first, last + 1) of an episode (0-based); a region shorter than an episode straddles the "
+                                    "first anoxic -> aerobic phase boundary (call 51, a double step) with the episode's own share of "
+                                    "anoxic calls; the episode is advanced untimed to call first - warmup"),
+                   "anoxic_share_of_timed_calls": frac_anoxic, "anoxic_share_of_an_episode": sum(anoxic_of) / len(anoxic_of),
                    "collective_backend": ("none" if not dist_up else "nccl (RCCL)" if backend == "nccl" else
                                           "gloo - REHEARSAL: %d ranks share %d GPU(s), not a scaling measurement" % (world, ndev)),
                    "ranks": dist.get_world_size() if dist_up else 1,
@@ -732,33 +987,38 @@ def main():
                    "rank_elapsed_ms": [t * 1e3 for t in rank_elapsed],
                    "rank_skew_ms": (max(rank_elapsed) - min(rank_elapsed)) * 1e3,
                    "rank_devices": rank_devices,
-                   "allgathers_in_timed_region": acct["allgathers"],
+                   "self_launched": os.environ.get("SBR_BENCH_SELF_LAUNCHED") == "1",
+                   "allgathers_in_timed_region": leg.acct["allgathers"],
                    "allgather_bytes_per_rank": 4 * n_local if dist_up else 0,
                    "opening_bracket": "synchronize, barrier, last warm-up step, synchronize",
                    "policy": args.policy,
                    "step_issue": ("eager: one ctypes call per step" if (args.no_graphs or fused) else
-                                  "HIP-graph replays of <= 64 captured sbr_step launches (%d graphs)" % len(graphs)),
-                   "actions": ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
-                               "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)")),
+                                  "HIP-graph replays of <= 64 captured sbr_step launches (%d graphs)" % len(leg.graphs)),
+                   "actions": (("the reference's own action model (get_available_actions, gym_SBR_oneshot.py:440-459): from [0, 15], each call "
+                                "moves each set-point by one of (-0.1, 0, +0.1) / (-5, 0, +5) inside [0, 8] x [0, 15]; float32, resident in HBM; "
+                                "influent scenarios 4..7") if args.policy == "walk" else
+                               ("per-call random set-points u_DO ~ U[0, %.1f], u_EC ~ U[0, 15], float32, resident in HBM; influent "
+                                "scenarios %s" % (do_max, "4..7 (4 + global id mod 4)" if physical else "0..7 (global id mod 8)"))),
                    "scheme": scheme, "library_source_hash": lib_hash,
                    "dosing_wave_call_share": dosing_share,
-                   "kernel": ("k_rollout<false,%d>" % scheme) if fused else "k_step<float,float,%d,false,%d,%d>" % (64 if n_local <= 49152 else 256, scheme, 2 if (scheme == 1 and n_local > 65536) else 1)},
+                   "kernel": step_kernel_label(env, scheme, fused)},
         "roofline": roofline,
         "env_status": {"near_pole_frac_last_episode": float(((st_bits & _capi.ST_NEAR_POLE) != 0).float().mean().item())
-                       if state["episode"] > 2 else None,
+                       if leg.state["episode"] > 2 else None,
                        "negative_frac_last_episode": float(((st_bits & _capi.ST_NEGATIVE) != 0).float().mean().item())
-                       if state["episode"] > 2 else None,
+                       if leg.state["episode"] > 2 else None,
                        "nonfinite": int(((st_bits & _capi.ST_NONFINITE) != 0).sum().item()),
                        "note": "sticky per-env flags of the last finished episode (SBR_ST_* in include/sbr_amd.h): the physical policy "
                                "keeps every env inside the model's domain; the uniform one drives ammonia negative in most envs (the "
-                               "reference model has no guards) - arithmetic cost is the same either way"},
+                               "reference model has no guards).  Under cfg.scheme = 1 the cost of a call depends on the states (step "
+                               "counts are chosen per env): see fp64_valu.b5_steps_per_interval"},
     }
     if cpu is not None:
         cpu = dict(cpu)
         cpu.pop("per_call", None)             # 3 x 463 floats: summarised above (fp64_valu, config.dosing_wave_call_share)
         out["cpu_baseline"] = cpu
     env.close()
-    if world > 1 or force_dist:
+    if dist_up:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

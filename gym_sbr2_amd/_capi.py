@@ -8,20 +8,24 @@ import os
 
 from . import build as _build
 
-NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 24, 10
+NX, NOBS, NSTATE, NACT, NCTRL, KLA_HIST = 14, 18, 15, 2, 25, 10
 NSCEN, NSERIES, NSAMP = 8, 14, 48
 NCYC_ACT, NCYC_OBS, NCYC_DIAG = 3, 3, 12
-ABI_VERSION = 5      # SBR_ABI_VERSION of include/sbr_amd.h; load() refuses a library that reports another
-NTRACE = 34          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
+ABI_VERSION = 6      # SBR_ABI_VERSION of include/sbr_amd.h; load() refuses a library that reports another
+NTRACE = 36          # per traced env and call (enum SBR_TR_* in sbr_amd.h)
 (TR_T, TR_X0, TR_KLA, TR_EC, TR_REWARD, TR_DONE, TR_U_DO, TR_U_EC, TR_E_EC, TR_IE_EC, TR_DCV_EC, TR_R_EQI, TR_R_OCI, TR_R_AE,
- TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST, TR_E_EC_FIRST, TR_IE_EC_FIRST, TR_DCV_EC_FIRST) = (
-     0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33)
+ TR_R_EC, TR_N_IV, TR_KLA_FIRST, TR_EC_FIRST, TR_E_EC_FIRST, TR_IE_EC_FIRST, TR_DCV_EC_FIRST, TR_PLAN, TR_PLAN_FIRST) = (
+     0, 1, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35)
 # rows of the ctrl block (enum in sbr_amd.h)
 C_T, C_SO_M1, C_SO_M2, C_SNO_M1, C_SNO_M2, C_IE_DO, C_IE_EC, C_EC_LAST = range(8)
 C_KLA_HIST0 = 8
 C_KLA_LAST = C_KLA_HIST0 + KLA_HIST - 1
-C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS, C_KLA_SUM = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
-                                                         C_KLA_LAST + 5, C_KLA_LAST + 6)
+C_QW, C_RETURN, C_STEPS, C_DONE, C_STATUS, C_KLA_SUM, C_PLAN = (C_KLA_LAST + 1, C_KLA_LAST + 2, C_KLA_LAST + 3, C_KLA_LAST + 4,
+                                                                 C_KLA_LAST + 5, C_KLA_LAST + 6, C_KLA_LAST + 7)
+PLAN_SLAVED = 128    # SBR_PLAN_SLAVED: C_PLAN / TR_PLAN = Butcher-5 step count of the env's last interval + this bit if So was held
+# sbr_query (enum SBR_Q_* in sbr_amd.h)
+(Q_ONE_WAVE_ENVS, Q_STEP_SMALL_BATCH_ENVS, Q_STEP_BLOCK, Q_STEP_WAVES, Q_STEP_TWO_WAVES_ABOVE_ENVS, Q_FUSED_ONE_WAVE_MAX_ENVS,
+ Q_ROLLOUT_WAVES, Q_RESET_BLOCK, Q_SCHEME) = range(9)
 ST_NEGATIVE, ST_NEAR_POLE, ST_NONFINITE = 1, 2, 4     # SBR_ST_* bits of the status row
 # cfg.reward_kind: module_reward_EQIOCI.py (SBROS-v1) / module_reward_continuous_G2ANET.py / module_reward_continuous.py
 REWARD_KINDS = {"eqi_oci": 0, "g2anet": 1, "oci": 2}
@@ -57,6 +61,7 @@ SYMBOLS = {
     "sbr_destroy": (C.c_int, [_VP]),
     "sbr_last_error": (C.c_char_p, [_VP]),
     "sbr_num_envs": (_I64, [_VP]),
+    "sbr_query": (C.c_int, [_VP, _I32, C.POINTER(C.c_int64)]),
     "sbr_set_influent_tables": (C.c_int, [_VP, _VP, _VP]),
     "sbr_reset": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "sbr_reset_carry": (C.c_int, [_VP, _U64, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -129,8 +129,9 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[
 //    count k is recovered from the running time, k = round((t - T_fill)/t_delta); a step writes ONE slot, not ten, and
 //    (round 4) READS three: next to the ring the handle keeps Kla[-1] and the sum of the eight entries before it, from which
 //    the reward's window follows incrementally (SbrHistInc in sbr_device.h);
-//  * steps, two flags, status bits and the done flag share one row (meta = steps*64 + m1i*32 + idle*16 + status*2 + done,
-//    an integer < 2^31 held in a double: steps saturate at 2^25 - 1 calls per episode);
+//  * steps, the plan of the last interval (round 6), two flags, status bits and the done flag share one row (meta = steps*16384 +
+//    plan*64 + m1i*32 + idle*16 + status*2 + done, an integer < 2^31 held in a double: steps saturate at 2^17 - 1 calls per
+//    episode; plan = SBR_C_PLAN's code, 8 bits);
 //  * So[-1] and Sno[-1] are IMPLICIT after an ordinary step (round 4): every interval ends with So.append(x_out[-1][8]),
 //    Sno.append(x_out[-1][9]) (:1955-1956, :2043-2044), so after a step the two values ARE x[8] and x[9] and k_step neither
 //    stores nor loads their rows (meta's m1i bit says so).  Whoever writes values that are NOT the plant's - the reset (Ss in
@@ -143,7 +144,7 @@ SBR_DEV void store_x(const SbrBuf& b, int64_t i0, uint32_t l, const double (&x)[
 // would take 20 + 24 rows (352 B) and rounds 2-3 took 18 + 11 (232 B).
 enum { R_T = 0, R_SO_M1, R_SNO_M1, R_IE_DO, R_IE_EC, R_EC_LAST, R_RET, R_META, R_KLA_LAST, R_W8, R_RING0,
        R_SO_M2 = R_RING0 + SBR_KLA_HIST, R_SNO_M2, R_QW, R_KSUM, R_NROWS };
-#define SBR_MAX_STEPS ((1 << 25) - 1)
+#define SBR_MAX_STEPS ((1 << 17) - 1)
 
 SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since reset, from the running time
     double q = __builtin_fma(t - p.T_fill, p.inv_t_delta, 0.5);
@@ -152,15 +153,20 @@ SBR_DEV int ring_k(const SbrPar& p, double t) {             // intervals since r
     return (int)q;
 }
 SBR_DEV int ring_wrap(int s) { return s >= SBR_KLA_HIST ? s - SBR_KLA_HIST : s; }       // for 0 <= s < 20
-// meta = steps*64 + m1i*32 + idle*16 + status*2 + done.  `idle`: the done call of k_step appended one more Kla than t accounts
+// meta = steps*16384 + plan*64 + m1i*32 + idle*16 + status*2 + done.  `plan`: what cfg.scheme = 1 did in the last control
+// interval k_step ran for this env (step count + 128 if dissolved oxygen was held; 0 = none reported: scheme 0, a reset, an
+// import, a rollout) - SBR_C_PLAN of the public layout; it rides in this row so that reporting it moves no extra byte.  `idle`: the done call of k_step appended one more Kla than t accounts
 // for (Sim_idle's, :2578): the ring's oldest entry then sits one slot further than ring_k(t) says (k_export adds it; a reset,
 // an import or a rollout store the ring in plain order and clear the bit).  `m1i`: So[-1], Sno[-1] are x[8], x[9], their rows
 // are stale (set by an ordinary k_step call only; every other writer stores the rows and leaves it clear).
 #define SBR_META_M1I 32
-#define SBR_META_STEPS_SHIFT 6
-SBR_DEV double meta_pack(int steps, int status, bool done, bool idle = false, bool m1i = false) {
-    return (double)((steps << SBR_META_STEPS_SHIFT) + (m1i ? SBR_META_M1I : 0) + (idle ? 16 : 0) + status * 2 + (done ? 1 : 0));
+#define SBR_META_PLAN_SHIFT 6
+#define SBR_META_STEPS_SHIFT 14
+SBR_DEV double meta_pack(int steps, int status, bool done, bool idle = false, bool m1i = false, int plan = 0) {
+    return (double)((steps << SBR_META_STEPS_SHIFT) + ((plan & 0xff) << SBR_META_PLAN_SHIFT) + (m1i ? SBR_META_M1I : 0) + (idle ? 16 : 0) +
+                    status * 2 + (done ? 1 : 0));
 }
+SBR_DEV int meta_plan(double m) { return ((int)m >> SBR_META_PLAN_SHIFT) & 0xff; }
 SBR_DEV void meta_unpack(double m, int& steps, int& status, bool& done, bool& idle, bool& m1i) {
     const int v = (int)m;
     done = (v & 1) != 0; status = (v >> 1) & 7; idle = (v & 16) != 0; m1i = (v & SBR_META_M1I) != 0; steps = v >> SBR_META_STEPS_SHIFT;
@@ -186,7 +192,7 @@ SBR_DEV void load_ctl_pre(const SbrBuf& b, int64_t i0, uint32_t l, bool need_m2,
     c.so_m2 = need_m2 ? CTRL(R_SO_M2) : c.so_m1;
     c.sno_m2 = need_m2 ? CTRL(R_SNO_M2) : c.sno_m1;
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
-    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9; c.plans = 0;
 }
 // rows every step rewrites (the ring slot(s), return and meta are written by the caller); with_m1 = false leaves So[-1] and
 // Sno[-1] implicit (the caller then sets meta's m1i bit)
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_export(SbrPar p, SbrBuf b, double
     for (int j = 0; j < SBR_KLA_HIST; ++j) v[SBR_C_KLA_HIST0 + j] = hist[j];
     v[SBR_C_QW] = CTRL(R_QW); v[SBR_C_RETURN] = CTRL(R_RET); v[SBR_C_STEPS] = (double)steps;
     v[SBR_C_DONE] = done ? 1.0 : 0.0; v[SBR_C_STATUS] = (double)status; v[SBR_C_KLA_SUM] = CTRL(R_KSUM);
+    v[SBR_C_PLAN] = (double)meta_plan(CTRL(R_META));
     if (only_row >= 0) {
 #pragma unroll
         for (int r = 0; r < SBR_NCTRL; ++r) if (r == only_row) out[i] = v[r];
@@ -260,7 +267,9 @@ __global__ __launch_bounds__(SBR_BLOCK) void k_import(SbrPar p, SbrBuf b, const 
     CTRL(R_QW) = IN(SBR_C_QW); CTRL(R_RET) = IN(SBR_C_RETURN); CTRL(R_KSUM) = IN(SBR_C_KLA_SUM);
     double st = IN(SBR_C_STEPS);
     st = st >= 0.0 ? (st < (double)SBR_MAX_STEPS ? st : (double)SBR_MAX_STEPS) : 0.0;
-    CTRL(R_META) = meta_pack((int)st, (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0);
+    double pl = IN(SBR_C_PLAN);
+    pl = pl >= 0.0 ? (pl < 255.0 ? pl : 255.0) : 0.0;       // also catches NaN
+    CTRL(R_META) = meta_pack((int)st, (int)IN(SBR_C_STATUS) & 7, IN(SBR_C_DONE) != 0.0, false, false, (int)pl);
 #undef IN
 }
 
@@ -620,6 +629,10 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BL
     constexpr int NSLOT = PARK ? SBR_NPARK_2W : SBR_NPARK;
     // parked values: slots SBR_PK_X6 + SBR_NXD + 1 + j, j < 20 (13 per interval + 7 of the call; 19 around the terminal phases)
     static_assert(!PARK || SBR_NPARK_2W >= SBR_PK_X6 + SBR_NXD + 1 + 20, "the LDS region of the two-waves build is too small for its parked values");
+    // ... and its upper bounds: static LDS is limited to 64 KiB per workgroup, and the two-waves build only pays while
+    // TWO of its workgroups fit the 160 KiB of a CU - one more __shared__ word would silently halve the residency
+    static_assert(sizeof(double) * NSLOT * BLK <= 65536, "k_step's parking region exceeds the 64 KiB static LDS limit");
+    static_assert(!PARK || 2 * sizeof(double) * NSLOT * BLK <= 160 * 1024, "two workgroups of the two-waves build must fit a CU's 160 KiB of LDS");
     __shared__ __attribute__((aligned(16))) double park[NSLOT * BLK];
     uint32_t l = threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.x * BLK;
@@ -646,7 +659,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BL
     const double meta0 = CTRL(R_META);
     c.t = CTRL(R_T); c.ie_do = CTRL(R_IE_DO); c.ie_ec = CTRL(R_IE_EC); c.ec_last = CTRL(R_EC_LAST);
     c.ec_prev = c.ec_last; c.u_do = 0.0; c.u_ec = 0.0;
-    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9;
+    c.n_new = 0; c.st_new = 0; c.span = 0.0; c.rows = 9; c.plans = 0;
     if ((flags & SBR_KF_NEED_M2) != 0u) { c.so_m2 = CTRL(R_SO_M2); c.sno_m2 = CTRL(R_SNO_M2); }
     const ActT* act = action + i0 * 2;
     const double a0 = (double)act[2 * l], a1 = (double)act[2 * l + 1];           // one 8- or 16-byte load per lane
@@ -757,7 +770,7 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BL
         // the m1i bit ("So[-1] / Sno[-1] are x[8] / x[9]") is claimed only by a call that RAN an interval: a call with
         // n_new == 0 (t injected as NaN) writes nothing to the memories, so it leaves them where they were - rows stay rows
         const bool m1i_new = dn ? false : (c.n_new > 0 ? true : !m1_rows);
-        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed, m1i_new));
+        st_out(&CTRL(R_META), meta_pack(steps < SBR_MAX_STEPS ? steps + 1 : steps, status | c.st_new, dn, idle_pushed, m1i_new, c.plans & 0xff));
         SBR_STAMP(10, false);                 // controller stores issued
         if (b.trace != nullptr && i0 + l < b.n_trace && (int64_t)steps < b.trace_cap) {     // trajectory export, off by default
             double* rec = b.trace + ((int64_t)steps * SBR_NTRACE) * b.n_trace + (i0 + l);
@@ -775,6 +788,8 @@ __global__ __launch_bounds__(BLK, BLK == 256 ? (WAVES == 2 ? 2 : SBR_STEP_MIN_BL
             // what rebuilding the sub-interval rows needs (sbr_eval_substeps): the intervals run and the first one's Kla / EC
             rec[SBR_TR_N_IV * b.n_trace] = (double)c.n_new; rec[SBR_TR_KLA_FIRST * b.n_trace] = c.knew[0];
             rec[SBR_TR_EC_FIRST * b.n_trace] = c.n_new > 1 ? c.ec_prev : c.ec_last;
+            // what cfg.scheme = 1 did (round 6): plan code of the call's last interval and of its first (equal when one ran)
+            rec[SBR_TR_PLAN * b.n_trace] = (double)(c.plans & 0xff); rec[SBR_TR_PLAN_FIRST * b.n_trace] = (double)((c.plans >> 8) & 0xff);
         }
     } else {
         x6.get(xa6);
@@ -1230,7 +1245,7 @@ static void launch_step(sbr_env* e, const void* action, void* obs, void* state, 
 
 extern "C" {
 
-const char* sbr_version(void) { return "sbr_amd 0.5.0 (gfx950, fp64; scheme 1 = adaptive Butcher-5, scheme 0 = RK4)"; }
+const char* sbr_version(void) { return "sbr_amd 0.6.0 (gfx950, fp64; scheme 1 = adaptive Butcher-5, scheme 0 = RK4)"; }
 int sbr_abi_version(void) { return SBR_ABI_VERSION; }
 
 int sbr_default_config(sbr_config* c) {
@@ -1292,6 +1307,7 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
     std::string bad;
     if (c.substeps < 1 || c.substeps > 10000) bad = "substeps out of range";
     if (c.scheme < 0 || c.scheme > 1) bad = "scheme must be 0 (RK4 x substeps) or 1 (adaptive Butcher-5)";
+    if (c.reserved_ != 0) bad = "reserved_ must be 0 (a caller that leaves it uninitialised could not be told from one using a later meaning)";
     if (!(c.Koa > 0 && c.Koa < 1e300)) bad = "Koa must be positive";
     if (c.reward_kind < 0 || c.reward_kind > 2) bad = "reward_kind must be 0 (EQI/OCI), 1 (G2ANET) or 2 (operating cost)";
     if (!(c.dt > 0) || !(c.t_delta > 0)) bad = "dt and t_delta must be positive";
@@ -1383,6 +1399,24 @@ int sbr_destroy(sbr_env* e) {
 }
 
 const char* sbr_last_error(const sbr_env* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int sbr_query(const sbr_env* e, int32_t what, int64_t* out) {
+    if (!e || !out) return SBR_ERR_INVALID;
+    const bool b5 = e->cfg.scheme == 1;
+    switch (what) {
+        case SBR_Q_ONE_WAVE_ENVS: *out = e->one_wave_envs; break;
+        case SBR_Q_STEP_SMALL_BATCH_ENVS: *out = SBR_SMALL_BATCH; break;
+        case SBR_Q_STEP_BLOCK: *out = e->n <= SBR_SMALL_BATCH ? 64 : 256; break;
+        case SBR_Q_STEP_WAVES: *out = (e->n > SBR_SMALL_BATCH && b5 && e->n > SBR_STEP_ONE_WAVE_ENVS(e)) ? 2 : 1; break;
+        case SBR_Q_STEP_TWO_WAVES_ABOVE_ENVS: *out = SBR_STEP_ONE_WAVE_ENVS(e) > SBR_SMALL_BATCH ? SBR_STEP_ONE_WAVE_ENVS(e) : SBR_SMALL_BATCH; break;
+        case SBR_Q_FUSED_ONE_WAVE_MAX_ENVS: *out = SBR_FUSED_ONE_WAVE_ENVS(e); break;
+        case SBR_Q_ROLLOUT_WAVES: *out = (b5 && e->n <= SBR_FUSED_ONE_WAVE_ENVS(e)) ? 1 : 2; break;
+        case SBR_Q_RESET_BLOCK: *out = e->n > e->one_wave_envs ? 512 : SBR_RESET_BLOCK; break;
+        case SBR_Q_SCHEME: *out = e->cfg.scheme; break;
+        default: return SBR_ERR_INVALID;
+    }
+    return SBR_OK;
+}
 int64_t sbr_num_envs(const sbr_env* e) { return e ? e->n : 0; }
 
 int sbr_set_influent_tables(sbr_env* e, const double* means, const double* stds) {

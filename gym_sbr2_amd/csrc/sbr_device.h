@@ -439,9 +439,10 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 // it exists (17 vector FMAs per step, at most five 9-vectors live) - with the step-size products h a_ij per lane in VGPRs.
 //   DOSE: the scaled-mass form of sbr_rk4_dose (w = c V/V0; the Monod constants at the five distinct stage times of a step,
 //   the constant source of Ss added to every stage slope); a lane with Q == 0 computes the plain form's values.
+// Returns the plan it ran with: step count (<= 64) + SBR_PLAN_SLAVED if dissolved oxygen was held (sbr_amd.h, SBR_C_PLAN).
 struct SbrB5C { double a21, a31, a42, a51, a54, a61, a62, a63, a65, b1, b3, b4; };
 template <bool DOSE>
-SBR_DEV void sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, double Q) {
+SBR_DEV int sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kla, double Q) {
     const double kla_sat = kla * p.So_sat;
     const double v0 = x[0], n0 = x[10] - x[9];
     double a[SBR_NA], k[SBR_NA], xp = x[7], e = 0.0, rs = 1.0;
@@ -563,12 +564,13 @@ SBR_DEV void sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double k
     sbr_scatter(a, x);
     x[7] = xp;
     x[13] = __builtin_fma(x[10] - x[9], c14, u);
+    return n + (slaved ? SBR_PLAN_SLAVED : 0);
 }
 // m macro intervals of span/m each, closed reactor (the idle phase of the done call: m = ceil(rows / 10))
 SBR_DEV void sbr_b5a_span(const SbrPar& p, double (&x)[SBR_NX], double span, int m, double kla) {
     const double hm = span * sbr_rcp((double)(m > 0 ? m : 1));
 #pragma unroll 1
-    for (int j = 0; j < m; ++j) sbr_b5a<false>(p, x, hm, kla, 0.0);
+    for (int j = 0; j < m; ++j) (void)sbr_b5a<false>(p, x, hm, kla, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -582,6 +584,7 @@ struct SbrCtl {
                               // that every phase is longer than t_delta, so a third interval cannot fire)
     int n_new;
     int st_new;               // SBR_ST_* bits raised by this call
+    int plans;                // scheme 1: plan code of the last interval run (bits 0-7) and of the call's first (bits 8-15); 0 under scheme 0
     double span;              // t_range[-1] - t_range[0] of the last interval
     int rows;                 // len(t_range) of the last interval: 9 or 10
 };
@@ -626,6 +629,14 @@ struct SbrX6LdsT {         // slot j of the lane lives at base[j * 64] inside it
     }
 };
 using SbrX6Lds = SbrX6LdsT<false>;
+
+// the small integers of SbrCtl as ONE exactly representable double (the parked build of k_step keeps them in an LDS slot):
+// rows (<= 10) | st_new (< 8) << 4 | n_new (<= 2) << 7 | plans (16 bits) << 9
+SBR_DEV double sbr_pack_small(const SbrCtl& c) { return (double)(c.rows + (c.st_new << 4) + (c.n_new << 7) + (c.plans << 9)); }
+SBR_DEV void sbr_unpack_small(double v, SbrCtl& c) {
+    const int pk = (int)v;
+    c.rows = pk & 15; c.st_new = (pk >> 4) & 7; c.n_new = (pk >> 7) & 3; c.plans = (pk >> 9) & 0xffff;
+}
 
 // Sticky domain-of-validity bits (SBR_ST_* in sbr_amd.h), evaluated on the end state of an interval.  x < -K/2 is
 // "within 50 % of the pole of x/(K+x)".  Pure bookkeeping: nothing in the dynamics reads it.
@@ -703,15 +714,16 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
         xs6.park(0, t1); xs6.park(1, c.so_m1); xs6.park(2, c.sno_m1); xs6.park(3, c.ie_do); xs6.park(4, c.ie_ec);
         xs6.park(5, c.ec_last); xs6.park(6, ec); xs6.park(7, c.u_do); xs6.park(8, c.u_ec); xs6.park(9, kla);
         xs6.park(10, c.knew[0]); xs6.park(11, span);
-        xs6.park(12, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows));       // three small integers (rows <= 10, status < 8): exact
+        xs6.park(12, sbr_pack_small(c));                  // rows, status bits, interval count, plans: small integers, exact
         asm volatile("" ::: "memory");
     }
+    int plan = 0;
     if constexpr (SCH == 1) {
 #ifdef SBR_B5_ONE_FORM
-        sbr_b5a<true>(p, x, span, kla, ec);
+        plan = sbr_b5a<true>(p, x, span, kla, ec);
 #else
-        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) sbr_b5a<false>(p, x, span, kla, 0.0);
-        else sbr_b5a<true>(p, x, span, kla, ec);
+        if (__builtin_amdgcn_ballot_w64(ec != 0.0) == 0ull) plan = sbr_b5a<false>(p, x, span, kla, 0.0);
+        else plan = sbr_b5a<true>(p, x, span, kla, ec);
 #endif
     } else {
         const double h = span * p.inv_substeps;
@@ -721,13 +733,13 @@ SBR_DEV void sbr_interval(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], X6& x
     if constexpr (X6::kPark) {
         asm volatile("" ::: "memory");
         t1r = xs6.unpark(0); klar = xs6.unpark(9); ecr = xs6.unpark(6); spanr = xs6.unpark(11);
-        const int pk = (int)xs6.unpark(12);
-        c.n_new = pk >> 16; c.st_new = (pk >> 4) & 0xfff; c.rows = pk & 15;
+        sbr_unpack_small(xs6.unpark(12), c);
         c.knew[0] = xs6.unpark(10);
         c.so_m1 = xs6.unpark(1); c.sno_m1 = xs6.unpark(2); c.ie_do = xs6.unpark(3); c.ie_ec = xs6.unpark(4);
         c.ec_last = xs6.unpark(5); c.u_do = xs6.unpark(7); c.u_ec = xs6.unpark(8);
     }
     if (c.n_new == 0) c.knew[0] = klar; else c.knew[1] = klar;    // n_new <= 2, see SbrCtl
+    c.plans = c.n_new == 0 ? (plan | (plan << 8)) : ((c.plans & 0xff00) | plan);
     c.n_new += 1;
     c.kla_last = klar;
     c.ec_prev = c.ec_last; c.ec_last = ecr;
@@ -758,7 +770,7 @@ template <bool LOOP, int SCH, typename X6, typename TR>
 SBR_DEV void sbr_run_intervals(const SbrPar& p, SbrCtl& c, double (&x)[SBR_NX], double a0, double a1, X6& xs6, const TR& tr) {
     a0 = a0 < 0.0 ? 0.0 : (a0 > p.act_DO_max ? p.act_DO_max : a0);       // :901-906
     a1 = a1 < 0.0 ? 0.0 : (a1 > p.act_EC_max ? p.act_EC_max : a1);       // :865-870
-    c.n_new = 0; c.st_new = 0;
+    c.n_new = 0; c.st_new = 0; c.plans = 0;
     c.knew[0] = c.kla_last; c.knew[1] = c.kla_last;      // defined even if no interval runs (t injected as NaN: sbr_phase = -1)
     if (LOOP) {
         int last = -1;
@@ -1056,7 +1068,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
                 q.park(0, r); q.park(1, rp.eqi2); q.park(2, rp.ae); q.park(3, rp.ec); q.park(4, c.t); q.park(5, c.so_m1);
                 q.park(6, c.so_m2); q.park(7, c.sno_m1); q.park(8, c.sno_m2); q.park(9, c.ie_ec); q.park(10, c.ec_last);
                 q.park(11, c.ec_prev); q.park(12, c.u_ec); q.park(13, c.knew[0]); q.park(14, c.knew[1]); q.park(15, c.span);
-                q.park(16, (double)(c.n_new * 65536 + c.st_new * 16 + c.rows)); q.park(17, snh_eff); q.park(18, ksum);
+                q.park(16, sbr_pack_small(c)); q.park(17, snh_eff); q.park(18, ksum);
                 asm volatile("" ::: "memory");
                 qw = sbr_terminal<SCH>(p, c, hs, x);
                 asm volatile("" ::: "memory");
@@ -1064,8 +1076,7 @@ SBR_DEV double sbr_finish_step(const SbrPar& p, SbrCtl& c, H& hs, double (&x)[SB
                 c.so_m1 = q.unpark(5); c.so_m2 = q.unpark(6); c.sno_m1 = q.unpark(7); c.sno_m2 = q.unpark(8);
                 c.ie_ec = q.unpark(9); c.ec_last = q.unpark(10); c.ec_prev = q.unpark(11); c.u_ec = q.unpark(12);
                 c.knew[0] = q.unpark(13); c.knew[1] = q.unpark(14); c.span = q.unpark(15);
-                const int pk3 = (int)q.unpark(16);
-                c.n_new = pk3 >> 16; c.st_new = (pk3 >> 4) & 0xfff; c.rows = pk3 & 15;
+                sbr_unpack_small(q.unpark(16), c);
                 if (OCI) {
                     ksum = q.unpark(18) + c.kla_last;
                     r = sbr_reward_oci(p, 2, c.kla_last, ksum, qw, q.unpark(17));

@@ -237,6 +237,18 @@ class SbrOSVec:
         _capi.check(self.lib.sbr_get_influent(self._h, _ptr(out), self._stream()), self._h)
         return out
 
+    def query(self, what):
+        """One of the library's own decisions for this handle (sbr_query, _capi.Q_*): launch shapes and their thresholds, which
+        depend on the device's CU count."""
+        out = C.c_int64()
+        _capi.check(self.lib.sbr_query(self._h, int(what), C.byref(out)), self._h)
+        return int(out.value)
+
+    def plan(self, out=None):
+        """What cfg.scheme = 1 did in each env's last control interval ([N] int64): Butcher-5 step count (& 127) and
+        _capi.PLAN_SLAVED if dissolved oxygen was held.  0 = nothing to report (cfg.scheme 0, or no step() since the reset)."""
+        return self.ctrl_row(_capi.C_PLAN, out).to(torch.int64)
+
     def status(self):
         """Sticky domain-of-validity bits per env (int64; _capi.ST_NEGATIVE | ST_NEAR_POLE | ST_NONFINITE): the
         reference model has no guards and can be driven to negative ammonia / a Monod pole by aggressive policies."""

@@ -40,7 +40,7 @@ extern "C" {
 #define SBR_KLA_HIST 10    /* Kla values the reward can look back on (current + 9) */
 /* controller/bookkeeping doubles per env exposed by sbr_get_state/sbr_set_state, in this order.  This is the PUBLIC
  * layout; the kernels keep a leaner internal one (Kla history as a ring, packed bookkeeping) and translate. */
-#define SBR_NCTRL 24
+#define SBR_NCTRL 25
 enum {
     SBR_C_T = 0,           /* running time t (days)                     gym_SBR_oneshot.py:1357 */
     SBR_C_SO_M1, SBR_C_SO_M2, SBR_C_SNO_M1, SBR_C_SNO_M2,   /* So[-1] So[-2] Sno[-1] Sno[-2]  :1959-1961 */
@@ -53,10 +53,21 @@ enum {
     SBR_C_STEPS,                                            /* step() calls since reset (as double) */
     SBR_C_DONE,                                             /* 1.0 once the episode ended */
     SBR_C_STATUS,                                           /* sticky SBR_ST_* bits since reset (as double) */
-    SBR_C_KLA_SUM                                           /* sum(Kla) of the episode's whole list, in append order:
+    SBR_C_KLA_SUM,                                          /* sum(Kla) of the episode's whole list, in append order:
                                                                the 252 reset entries (:323), one per interval, idle's.
                                                                Advanced only with reward_kind 2 (else: its reset value) */
+    SBR_C_PLAN                                              /* (round 6) what cfg.scheme = 1 did in the LAST control interval
+                                                               sbr_step ran for this env: its Butcher-5 step count (1 .. 64)
+                                                               + SBR_PLAN_SLAVED if dissolved oxygen was held during the
+                                                               steps.  0 = nothing to report: cfg.scheme = 0, no sbr_step
+                                                               since the reset / sbr_set_state / sbr_rollout.  The reference's
+                                                               counterpart is LSODA's infodict (nst, nfe) at its odeint call
+                                                               sites (gym_SBR_oneshot.py:1953, :2041).  sbr_set_state keeps
+                                                               the value given (0 .. 255).  Costs no memory traffic: it shares
+                                                               the internal row of steps / status / done */
 };
+#define SBR_PLAN_SLAVED 128
+#define SBR_PLAN_STEPS(code) ((int)(code) & 127)
 /* (The reference's u_DO / u_EC globals and the EC value before EC[-1] are temporaries of one step() call - every
  * interval overwrites them before use - so they are not part of the state.) */
 
@@ -129,7 +140,8 @@ typedef struct sbr_config {
                                   reference's trajectories than scheme 0 (closed loop, worst 0.36 of the 1e-5 gate against 0.51).
                                   `substeps` then only sets the fill intervals of sbr_cycle_step; the idle phase is cut into
                                   ceil(rows / 10) macro intervals.  sbr_eval_substeps replays RK4 nodes under either scheme. */
-    int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; must be 0 */
+    int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; MUST be 0: sbr_create rejects anything else with
+                                  SBR_ERR_INVALID (round 6), so that a later round can give the word a meaning */
 } sbr_config;
 
 typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for N envs on one GPU */
@@ -138,8 +150,9 @@ typedef struct sbr_env sbr_env;      /* opaque handle: owns all device state for
 const char* sbr_version(void);
 /* Bumped whenever a signature, a struct layout or a record width of this header changes.  A consumer compiled against this
  * header checks sbr_abi_version() == SBR_ABI_VERSION once after loading the library (round 4 = 4: sbr_set_trace takes the
- * record width, SBR_NTRACE = 34; round 5 = 5: sbr_config.scheme). */
-#define SBR_ABI_VERSION 5
+ * record width, SBR_NTRACE = 34; round 5 = 5: sbr_config.scheme; round 6 = 6: SBR_NCTRL = 25 with SBR_C_PLAN, SBR_NTRACE = 36 with
+ * SBR_TR_PLAN / SBR_TR_PLAN_FIRST, sbr_query, sbr_config.reserved_ checked). */
+#define SBR_ABI_VERSION 6
 int sbr_abi_version(void);
 int sbr_default_config(sbr_config* cfg);
 int sbr_device_count(void);          /* HIP devices visible; 0 if none (never throws) */
@@ -158,6 +171,23 @@ int sbr_create(int64_t n_envs, int device_id, int64_t first_env_id, const sbr_co
 int sbr_destroy(sbr_env* env);
 const char* sbr_last_error(const sbr_env* env /* NULL = creation errors */);
 int64_t sbr_num_envs(const sbr_env* env);
+
+/* What the library decided for this handle from its size and the device it sits on (round 6).  The launch shapes depend on the
+ * device's CU count - a partitioned MI355X has fewer than 256 - so a consumer that wants to NAME the kernel a handle runs
+ * (bench.py's `config.kernel`, a profiler's filter) asks instead of repeating thresholds.  out receives one integer. */
+enum {
+    SBR_Q_ONE_WAVE_ENVS = 0,            /* envs that put one wavefront on every SIMD of the device: CUs x 4 x 64 (MI355X: 65536) */
+    SBR_Q_STEP_SMALL_BATCH_ENVS,        /* up to this many envs sbr_step launches 64-thread workgroups (49152) */
+    SBR_Q_STEP_BLOCK,                   /* workgroup size of THIS handle's sbr_step launches: 64 or 256 */
+    SBR_Q_STEP_WAVES,                   /* 1 or 2: which register budget of k_step THIS handle runs (2 = two waves per SIMD:
+                                           cfg.scheme = 1 and more envs than SBR_Q_STEP_TWO_WAVES_ABOVE_ENVS) */
+    SBR_Q_STEP_TWO_WAVES_ABOVE_ENVS,
+    SBR_Q_FUSED_ONE_WAVE_MAX_ENVS,      /* up to this many envs sbr_rollout / sbr_cycle_step run their uncapped-register build */
+    SBR_Q_ROLLOUT_WAVES,                /* 1 or 2 for THIS handle's sbr_rollout (and sbr_cycle_step under cfg.scheme = 1) */
+    SBR_Q_RESET_BLOCK,                  /* workgroup size of THIS handle's sbr_reset launches: 256 or 512 */
+    SBR_Q_SCHEME                        /* cfg.scheme in force */
+};
+int sbr_query(const sbr_env* env, int32_t what, int64_t* out);
 
 /* influent data: replaces the literals of buffer_tank3.py:18-1197.  means/stds are HOST pointers,
  * [SBR_NSCEN][SBR_NSERIES][SBR_NSAMP] float64; copied to the device once. */
@@ -194,12 +224,15 @@ int sbr_reset_carry(sbr_env* env, uint64_t seed, const int32_t* scenario, const 
  * the FIRST of them (equal to SBR_TR_KLA / SBR_TR_EC when the call ran one); and (round 4) the NO3-PID's e_EC, ie_EC, dcv_EC
  * of that FIRST interval too: the reference appends to these three lists once per INTERVAL (:1918-1926, :2006-2014), so a
  * phase-boundary call contributes two entries each (equal to SBR_TR_E_EC / _IE_EC / _DCV_EC when the call ran one).
- * record_width must be SBR_NTRACE of the header the caller was compiled against: the record grew from 28 to 31 to 34 doubles
+ * (Round 6) SBR_TR_PLAN / SBR_TR_PLAN_FIRST: what cfg.scheme = 1 did in the call's last / first interval, coded like SBR_C_PLAN
+ * (step count + SBR_PLAN_SLAVED; equal when the call ran one interval; 0 under cfg.scheme = 0).
+ * record_width must be SBR_NTRACE of the header the caller was compiled against: the record grew from 28 to 31 to 34 to 36 doubles
  * over the rounds, and a buffer sized for an older width would be overrun silently - a mismatch is SBR_ERR_INVALID. */
-#define SBR_NTRACE 34
+#define SBR_NTRACE 36
 enum { SBR_TR_T = 0, SBR_TR_X0 = 1, SBR_TR_KLA = 15, SBR_TR_EC, SBR_TR_REWARD, SBR_TR_DONE, SBR_TR_U_DO, SBR_TR_U_EC,
        SBR_TR_E_EC, SBR_TR_IE_EC, SBR_TR_DCV_EC, SBR_TR_R_EQI, SBR_TR_R_OCI, SBR_TR_R_AE, SBR_TR_R_EC,
-       SBR_TR_N_IV, SBR_TR_KLA_FIRST, SBR_TR_EC_FIRST, SBR_TR_E_EC_FIRST, SBR_TR_IE_EC_FIRST, SBR_TR_DCV_EC_FIRST };
+       SBR_TR_N_IV, SBR_TR_KLA_FIRST, SBR_TR_EC_FIRST, SBR_TR_E_EC_FIRST, SBR_TR_IE_EC_FIRST, SBR_TR_DCV_EC_FIRST,
+       SBR_TR_PLAN, SBR_TR_PLAN_FIRST };
 int sbr_set_trace(sbr_env* env, double* buf, int64_t n_envs, int64_t capacity, int32_t record_width);
 
 /* step: replaces SbrOS.step(action) (gym_SBR_oneshot.py:843-1273): phase logic, both PIDs,
@@ -247,7 +280,7 @@ int sbr_get_state(sbr_env* env, double* x, double* ctrl, void* stream);
 int sbr_set_state(sbr_env* env, const double* x, const double* ctrl, void* stream);
 
 /* one row of the ctrl block (SBR_C_* index), e.g. SBR_C_RETURN for the episode returns: out is [N] float64, DEVICE
- * pointer; asynchronous on `stream`, no host synchronisation (sbr_get_state translates all 23 rows). */
+ * pointer; asynchronous on `stream`, no host synchronisation (sbr_get_state translates all SBR_NCTRL rows). */
 int sbr_get_ctrl_row(sbr_env* env, int32_t row, double* out, void* stream);
 
 /* the flow-weighted influent each env was reset with (buffer_tank3.py:87-107; entry 0 = Qin/T_fill,

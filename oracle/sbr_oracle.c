@@ -54,8 +54,10 @@ typedef struct {
     double span;                    /* t_range[-1]-t_range[0] of the last interval */
     int32_t n_rows;                 /* 9 or 10: len(t_range) of the last interval */
     int32_t n_intervals;            /* intervals run by the last step() call */
-    int32_t scheme_steps;           /* scheme 1: step count of the last interval (0 = fell back to the RK4 substeps) */
-    int32_t pad_;
+    int32_t scheme_steps;           /* scheme 1: step count of the last interval (-1: scheme 0) */
+    int32_t scheme_plan;            /* the product's plan codes (SBR_C_PLAN / SBR_TR_PLAN, include/sbr_amd.h): bits 0-7 = step count of
+                                       the LAST interval of the last step() call + 128 if dissolved oxygen was held, bits 8-15 = the
+                                       same for the call's FIRST interval (equal when it ran one); 0 under scheme 0 */
 } sbro_env;
 
 static double status_bits(const sbro_params* p, const double* x, double status);
@@ -252,7 +254,7 @@ static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, 
     if (hold_so) k[8] = 0.0;
 }
 
-/* one macro interval; returns the step count */
+/* one macro interval; returns the plan code: step count + 128 if So was held (slaved) */
 static int b5a_macro(const sbro_params* p, int kind, double* x, double span, double kla, double ec) {
     static const double A21 = 0.25, A31 = 0.125, A32 = 0.125, A42 = -0.5, A43 = 1.0, A51 = 3.0 / 16.0, A54 = 9.0 / 16.0,
                         A61 = -3.0 / 7.0, A62 = 2.0 / 7.0, A63 = 12.0 / 7.0, A64 = -12.0 / 7.0, A65 = 8.0 / 7.0,
@@ -322,10 +324,10 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
         for (int i = 1; i < NX; ++i) x[i] = x[i] / s_end;
     }
     if (slaved) x[8] = x[8] / (1.0 + lam0 * span);
-    return n;
+    return n + (slaved ? 128 : 0);
 }
 
-/* m macro intervals of span/m each; returns the step count of the last one */
+/* m macro intervals of span/m each; returns the plan code of the last one */
 static int b5a_span(const sbro_params* p, int kind, double* x, double span, int m, double kla, double ec) {
     const double hm = span / m;
     int n = 0;
@@ -334,10 +336,18 @@ static int b5a_span(const sbro_params* p, int kind, double* x, double span, int 
 }
 
 /* scheme-aware integration of one reaction interval (python: SbrOsRef._integrate); returns the step count (-1: scheme 0) */
-int sbro_reaction_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
+static int reaction_interval_plan(const sbro_params* p, double* x, double span, double kla, double ec) {
     if (p->scheme == 1) return b5a_span(p, 0, x, span, 1, kla, ec);
     rk4_span(p, 0, x, span, p->substeps, kla, ec, 0);
     return -1;
+}
+int sbro_reaction_interval(const sbro_params* p, double* x, double span, double kla, double ec) {
+    const int plan = reaction_interval_plan(p, x, span, kla, ec);
+    return plan < 0 ? plan : (plan & 127);
+}
+/* the same, returning the plan code (step count + 128 if slaved; -1: scheme 0) */
+int sbro_reaction_interval_plan(const sbro_params* p, double* x, double span, double kla, double ec) {
+    return reaction_interval_plan(p, x, span, kla, ec);
 }
 
 /* the idle phase (kind 2) under the handle's scheme: scheme 1 cuts its `rows` RK4-substep-long span into ceil(rows/10) macro
@@ -522,7 +532,12 @@ static void interval(const sbro_params* p, sbro_env* e, int aerobic) {
     if (ec < p->EC_min) { ec = p->EC_min; e->ie_ec = e->ie_ec - err2 * p->dt; }
     else if (ec > p->EC_max) { ec = p->EC_max; e->ie_ec = e->ie_ec - err2 * p->dt; }
     memcpy(e->x_start, e->x, sizeof e->x_start);
-    e->scheme_steps = sbro_reaction_interval(p, e->x, t1 - t0, kla, ec);
+    {
+        const int plan = reaction_interval_plan(p, e->x, t1 - t0, kla, ec);
+        const int code = plan < 0 ? 0 : plan;
+        e->scheme_steps = plan < 0 ? plan : (plan & 127);
+        e->scheme_plan = e->n_intervals == 0 ? (code | (code << 8)) : ((e->scheme_plan & 0xff00) | code);
+    }
     for (int j = 0; j < KLA_HIST - 1; ++j) e->kla_hist[j] = e->kla_hist[j + 1];
     e->kla_hist[KLA_HIST - 1] = kla;
     e->kla_sum = e->kla_sum + kla;
@@ -679,7 +694,7 @@ void sbro_step(const sbro_params* p, sbro_env* e, const double* action, double* 
     double a0 = action[0], a1 = action[1];   /* float64, like the reference; the product takes float32 */
     a0 = a0 < 0 ? 0 : (a0 > p->act_DO_max ? p->act_DO_max : a0);
     a1 = a1 < 0 ? 0 : (a1 > p->act_EC_max ? p->act_EC_max : a1);
-    e->n_intervals = 0;
+    e->n_intervals = 0; e->scheme_plan = 0;
     /* four sequential tests on the running time (:860, :896, :931, :963) */
     if (e->t < p->T3_0) { e->u_ec = a1; e->u_do = 0; interval(p, e, 0); }
     if (e->t >= p->T3_0 && e->t <= p->T3_end) { e->u_do = a0; e->u_ec = 0; interval(p, e, 1); }

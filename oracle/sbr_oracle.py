@@ -35,7 +35,7 @@ class Env(C.Structure):
                 ("kla_hist", C.c_double * KLA_HIST),
                 ("qw", C.c_double), ("ret", C.c_double), ("steps", C.c_double), ("done", C.c_double),
                 ("status", C.c_double), ("kla_sum", C.c_double), ("influent", C.c_double * NX), ("x_start", C.c_double * NX), ("span", C.c_double),
-                ("n_rows", C.c_int32), ("n_intervals", C.c_int32), ("scheme_steps", C.c_int32), ("pad_", C.c_int32)]
+                ("n_rows", C.c_int32), ("n_intervals", C.c_int32), ("scheme_steps", C.c_int32), ("scheme_plan", C.c_int32)]
 
 
 ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "f8"), ("sno_m1", "f8"),
@@ -44,7 +44,7 @@ ENV_DTYPE = np.dtype([("x", "f8", NX), ("t", "f8"), ("so_m1", "f8"), ("so_m2", "
                       ("qw", "f8"), ("ret", "f8"), ("steps", "f8"), ("done", "f8"), ("status", "f8"), ("kla_sum", "f8"),
                       ("influent", "f8", NX),
                       ("x_start", "f8", NX), ("span", "f8"), ("n_rows", "i4"), ("n_intervals", "i4"), ("scheme_steps", "i4"),
-                      ("pad_", "i4")], align=True)
+                      ("scheme_plan", "i4")], align=True)
 
 
 def _src_hash():

@@ -137,3 +137,102 @@ def test_design_per_scenario_table_is_generated_from_the_committed_json():
     # the bench's own workload (physical policy on scenarios 4..7) stays inside the model's domain for the whole episode
     assert all(rec["episodes"]["scn%d_phys" % s]["valid_calls"] == 463 and rec["episodes"]["scn%d_phys" % s]["domain_exit_call"] == -1
                for s in (4, 5, 6, 7))
+
+
+def test_episode_schedule_and_the_timed_window():
+    """which calls of an episode are anoxic / aerobic comes from the reference's own phase tests on the running
+    time (bench.episode_schedule), pinned here to the reference-captured interval log; the driver's 20-step region is placed across
+    the first anoxic -> aerobic boundary with the episode's own mix (until round 5 it was calls 5..24, all anoxic, and the
+    constant bench.py used for the anoxic calls, [(0, 46), (235, 405)], was wrong)."""
+    import numpy as np
+    from conftest import golden
+    sched = bench.episode_schedule()
+    e = golden("sbros_const_2_5")
+    assert len(sched) == 463 == bench.CALLS_PER_EPISODE
+    per_call = [tuple(int(k) for k in e["iv_kind"][e["iv_call"] == c]) for c in range(463)]
+    assert sched == per_call                                             # every interval of every call, double steps included
+    assert [c for c, k in enumerate(sched) if len(k) == 2] == [51, 275, 462] and sched[51] == (0, 1) and sched[275] == (1, 0)
+    from gym_sbr2_amd import _capi
+    assert bench.episode_schedule(_capi.default_config()) == sched       # ... also from the library's own default config
+    anoxic = sum(1 for k in sched if k[-1] == 0)
+    assert anoxic == 238
+    # the driver's command: 20 timed calls after 5 warm-up calls -> calls 41 .. 60, ten of them anoxic
+    assert bench.timed_window_start(20, 5, sched) == 41
+    w = range(41, 61)
+    assert sum(1 for c in w if sched[c][-1] == 0) == 10 and 51 in w
+    # regions of an episode or more start at call W, as before; tiny regions still contain the boundary call
+    assert bench.timed_window_start(1852, 50, sched) == 50 and bench.timed_window_start(463, 50, sched) == 50
+    assert bench.timed_window_start(2, 0, sched) == 50 and bench.timed_window_start(400, 5, sched) == 5
+    for k in (1, 2, 5, 20, 64, 100, 300, 462):
+        s0 = bench.timed_window_start(k, 5, sched)
+        assert 0 <= s0 <= 463 - k and (k < 2 or s0 <= 51 < s0 + k)      # (a region that nearly fills the episode starts the warm-up in the episode before)
+    # no stale text: the docstring no longer calls config2 "RK4 h = dt", nor the uniform policy's cost data-independent
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "per-step API, RK4 h = dt" not in src and "cost is data-independent" not in src and "arithmetic cost is the same either way" not in src
+
+
+def test_walk_policy_is_the_reference_action_model():
+    """--policy walk: get_available_actions (gym_SBR_oneshot.py:440-459) - deltas (-0.1, 0, +0.1) / (-5, 0, +5) inside [0, 8] x [0, 15],
+    from u_DO = 0, u_EC = 15 (:212-213); a move that is not available leaves the set-point where it is."""
+    import numpy as np
+    rs = np.random.RandomState(0)
+    cur = np.column_stack([np.zeros(1000), np.full(1000, 15.0)])
+    seen_do, seen_ec = set(), set()
+    for _ in range(463):
+        nxt = bench.walk_move(cur, rs.randint(0, 3, (1000, 2)), np)
+        d = np.round(nxt - cur, 10)
+        seen_do |= set(d[:, 0].tolist()); seen_ec |= set(d[:, 1].tolist())
+        assert nxt[:, 0].min() >= 0 and nxt[:, 0].max() <= 8 and nxt[:, 1].min() >= 0 and nxt[:, 1].max() <= 15
+        cur = nxt
+    assert seen_do == {-0.1, 0.0, 0.1} and seen_ec == {-5.0, 0.0, 5.0}
+    assert set(np.unique(cur[:, 1]).tolist()) <= {0.0, 5.0, 10.0, 15.0}
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch, capsys):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment spawns
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <args>` as a
+    CHILD process (never an exec, before torch or a GPU is touched) and relays rank 0's JSON line and the return code."""
+    import subprocess
+    import sys
+    import pytest
+    calls = {}
+
+    class Done:
+        returncode = 0
+        stdout = 'NCCL version banner\n{"metric": "env-steps/sec (batched)", "n_gpus": 2, "config": {"ranks": 2}}\n'
+
+    def fake_run(cmd, **kw):
+        calls["cmd"], calls["kw"] = cmd, kw
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(os, "execv", lambda *a: (_ for _ in ()).throw(AssertionError("exec")))
+    before = set(sys.modules)
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert ex.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+    assert calls["kw"]["env"]["SBR_BENCH_SELF_LAUNCHED"] == "1" and "WORLD_SIZE" not in calls["kw"]["env"]
+    out = capsys.readouterr()
+    lines = [l for l in out.out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["config"]["ranks"] == 2 and "NCCL version banner" in out.err
+    # a child that fails, or prints no line, is an error of this command too
+    Done.returncode, Done.stdout = 3, ""
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "4"])
+    assert ex.value.code == 3
+    Done.returncode = 0
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "4"])
+    assert ex.value.code == 1
+    # under a launcher (WORLD_SIZE set) nothing is spawned: the rank count must match --gpus
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    calls.clear()
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "2"])
+    assert "cmd" not in calls and "WORLD_SIZE=3" in str(ex.value.code)

@@ -35,7 +35,14 @@ def test_header_constants_match_the_binding():
     assert (defs["SBR_NX"], defs["SBR_NOBS"], defs["SBR_NSTATE"], defs["SBR_NCTRL"], defs["SBR_KLA_HIST"]) == (
         _capi.NX, _capi.NOBS, _capi.NSTATE, _capi.NCTRL, _capi.KLA_HIST)
     assert (defs["SBR_ST_NEGATIVE"], defs["SBR_ST_NEAR_POLE"], defs["SBR_ST_NONFINITE"]) == (1, 2, 4)
-    assert _capi.C_STATUS == 22 and _capi.C_KLA_SUM == _capi.NCTRL - 1 == 23 and _capi.C_KLA_LAST == _capi.C_KLA_HIST0 + 9 == 17
+    assert _capi.C_STATUS == 22 and _capi.C_KLA_SUM == 23 and _capi.C_PLAN == _capi.NCTRL - 1 == 24 and _capi.C_KLA_LAST == _capi.C_KLA_HIST0 + 9 == 17
+    assert defs["SBR_PLAN_SLAVED"] == _capi.PLAN_SLAVED == 128 and defs["SBR_NTRACE"] == _capi.NTRACE and defs["SBR_ABI_VERSION"] == _capi.ABI_VERSION == 6
+    tr = re.findall(r"SBR_TR_[A-Z_0-9]+", text.split("enum { SBR_TR_T")[1].split("};")[0])
+    assert tr[-2:] == ["SBR_TR_PLAN", "SBR_TR_PLAN_FIRST"] and (_capi.TR_PLAN, _capi.TR_PLAN_FIRST) == (34, 35) == (_capi.NTRACE - 2, _capi.NTRACE - 1)
+    q = re.findall(r"^\s+(SBR_Q_[A-Z_]+)", text.split("int sbr_query")[0].split("enum {")[-1], re.M)
+    assert q == ["SBR_Q_" + n[2:] for n in ("Q_ONE_WAVE_ENVS", "Q_STEP_SMALL_BATCH_ENVS", "Q_STEP_BLOCK", "Q_STEP_WAVES", "Q_STEP_TWO_WAVES_ABOVE_ENVS",
+                                           "Q_FUSED_ONE_WAVE_MAX_ENVS", "Q_ROLLOUT_WAVES", "Q_RESET_BLOCK", "Q_SCHEME")]
+    assert [getattr(_capi, n[4:]) for n in q] == list(range(9))
     enum_names = re.findall(r"SBR_C_[A-Z_0-9]+", text.split("enum {")[1].split("};")[0])
     assert enum_names[:8] == ["SBR_C_T", "SBR_C_SO_M1", "SBR_C_SO_M2", "SBR_C_SNO_M1", "SBR_C_SNO_M2", "SBR_C_IE_DO", "SBR_C_IE_EC",
                               "SBR_C_EC_LAST"]
