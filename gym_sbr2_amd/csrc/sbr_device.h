@@ -437,8 +437,17 @@ SBR_DEV void sbr_rk4(const SbrPar& p, double (&x)[SBR_NX], double h, int n, doub
 // out of the later iterations: an env's bits do not depend on which envs share its wavefront (as with the dosing ballot).
 // The steps are written in running-sum form - each stage slope is added to the pending stage bases and the result as soon as
 // it exists (17 vector FMAs per step, at most five 9-vectors live) - with the step-size products h a_ij per lane in VGPRs.
+//   * (round 6: a further floor from the decay rates of the Ss / Snh / Sno modes themselves, n >= floor(j span / 2.5) + 1, was built
+//     and measured - without effect on any reference-regime interval, it removes half of the blow-ups of a plant with 4 x faster
+//     kinetics - and NOT adopted: three more wave-uniform constants in the plan cost k_step 55 more SGPR spill moves per call,
+//     +0.2 us of 11.7 (profiles/r06_notes.md).  The validity domain is stated next to `scheme` in sbr_amd.h instead.)
 //   DOSE: the scaled-mass form of sbr_rk4_dose (w = c V/V0; the Monod constants at the five distinct stage times of a step,
 //   the constant source of Ss added to every stage slope); a lane with Q == 0 computes the plain form's values.
+//   (Round 6 also built a QUASI-STEADY rule for the knee branch - when aeration balances uptake inside the knee nothing moves, and
+//   stability alone, max(2, floor(z / 2.5) + 1) steps, would do: applied to control intervals it put the per-cycle env's cycle-end
+//   state 0.55 of the gate off (a controller acts on So every interval and feeds the error back); applied to the idle phase of
+//   the done call only (Kla held) it was accurate, 0.0036 of the gate, and took 231 -> 204 us off that call = 0.06 us per call of
+//   an episode: measured, not adopted.  profiles/r06_notes.md section 2; scripts/analysis/knee_study.py idle.)
 // Returns the plan it ran with: step count (<= 64) + SBR_PLAN_SLAVED if dissolved oxygen was held (sbr_amd.h, SBR_C_PLAN).
 struct SbrB5C { double a21, a31, a42, a51, a54, a61, a62, a63, a65, b1, b3, b4; };
 template <bool DOSE>

@@ -139,7 +139,22 @@ typedef struct sbr_config {
                                   half-saturation constant within the interval: ~10 evaluations per interval, and closer to the
                                   reference's trajectories than scheme 0 (closed loop, worst 0.36 of the 1e-5 gate against 0.51).
                                   `substeps` then only sets the fill intervals of sbr_cycle_step; the idle phase is cut into
-                                  ceil(rows / 10) macro intervals.  sbr_eval_substeps replays RK4 nodes under either scheme. */
+                                  ceil(rows / 10) macro intervals.  sbr_eval_substeps replays RK4 nodes under either scheme.
+                                  VALIDITY DOMAIN of scheme 1 (round 6).  The step count is a start-of-interval plan, not an error
+                                  estimate.  What it bounds by construction: the oxygen mode's rate times the step (<= 2.5 of
+                                  Butcher-5's real stability limit 3.39, whatever the kinetic constants and the biomass).  What it
+                                  ASSUMES: every other mode (uptake of Ss, Snh, Sno; hydrolysis) has |lambda| * t_delta below
+                                  ~2.5 - with the reference's constants they stay below 1.0 on every captured interval, 2.2 in
+                                  the idle phase's thickened sludge.  Pinned to the reference on 24 fitted + 10 held-out
+                                  episodes (closed loop <= 0.373 of the gate), 36 000 intervals of the per-cycle env, and probed
+                                  off-regime: on random states of a plant with muH, muA, kh up to 4 x faster it misses the gate
+                                  on 134 of 2 836 states (11 beyond 30 gates) where scheme 0 misses 420 (239): scheme 0's fixed
+                                  h = dt is unstable once the oxygen rate times dt exceeds 2.785, scheme 1's count grows with
+                                  it (tests/test_oracle_golden.py::test_scheme1_under_perturbed_kinetic_constants,
+                                  ..._plan_on_states_far_from_the_reference_regime).  A configuration with kinetics several
+                                  times faster than the reference's or a longer t_delta is outside what either scheme was
+                                  validated on: check it against a fine solution (sbr_eval_substeps with many substeps) first.
+                                  What scheme 1 did is observable per env and call: SBR_C_PLAN, SBR_TR_PLAN. */
     int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; MUST be 0: sbr_create rejects anything else with
                                   SBR_ERR_INVALID (round 6), so that a later round can give the word a meaning */
 } sbr_config;

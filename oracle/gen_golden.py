@@ -539,6 +539,50 @@ def scenario_cases():
     return cases
 
 
+def heldout_cases(M):
+    """Round 6: HELD-OUT episodes.  The thresholds of the library's adaptive integrator (cfg.scheme = 1: 0.3 / 1.0 /
+    2.5, the slaved test, two slaved steps) were fitted on the 24 episodes above; these ten are excluded from any fitting, then and
+    in future rounds - they are only ever compared against.  New influent seeds; scenarios 4..7 (the bench's) and 1, 2 of the
+    low-ammonia ones; three policy shapes none of the fitted episodes has:
+      walk    - the reference's OWN action model: from u_DO = 0, u_EC = 15 (gym_SBR_oneshot.py:212-213) every call moves each
+                set-point by one of the deltas of SbrOS.get_available_actions (:440-459: [-0.1, 0, 0.1] / [-5, 0, 5] inside
+                [0, 8] x [0, 15]), drawn uniformly among the moves that function reports as available (it is CALLED here);
+      held20  - seeded set-points U[0, 2.5] x U[0, 15] held for 20 calls each;
+      sine    - u_DO = 0.8 + 0.8 sin(2 pi k / 37) sweeping the oxygen knee (0 .. 1.6 g/m3), u_EC = 7.5 + 7.5 sin(2 pi k / 53)."""
+    n = 470
+    env = M.SbrOS()
+    deltas = ([-0.1, 0.0, 0.1], [-5.0, 0.0, 5.0])
+    cases = {}
+
+    def walk(seed):
+        rs = np.random.RandomState(seed)
+        pre, acts = [0.0, 15.0], []
+        for _ in range(n):
+            avail = env.get_available_actions(pre, 2, 3)
+            nxt = []
+            for agent in range(2):
+                idx = np.flatnonzero(np.asarray(avail[agent]) == 1)
+                nxt.append(pre[agent] + deltas[agent][int(rs.choice(idx))])
+            acts.append(nxt)
+            pre = nxt
+        return np.asarray(acts, dtype=np.float64)
+
+    def held20(seed):
+        rs = np.random.RandomState(seed)
+        base = np.column_stack([rs.uniform(0, 2.5, n // 20 + 1), rs.uniform(0, 15, n // 20 + 1)])
+        return np.repeat(base, 20, axis=0)[:n]
+
+    k = np.arange(n)
+    sine = np.column_stack([0.8 + 0.8 * np.sin(2 * np.pi * k / 37.0), 7.5 + 7.5 * np.sin(2 * np.pi * k / 53.0)])
+    for s in (4, 5, 6, 7):
+        cases["ho_walk_s%d" % s] = (9100 + s, walk(9100 + s), s)
+    for s in (4, 6, 1):
+        cases["ho_held20_s%d" % s] = (9200 + s, held20(9200 + s), s)
+    for s in (5, 7, 2):
+        cases["ho_sine_s%d" % s] = (9300 + s, sine.copy(), s)
+    return cases
+
+
 # slim record of a scenario episode: everything the bit-identity, open-loop and closed-loop tests read; not the 9-or-10
 # LSODA output rows of every interval nor the dense trajectory lists (pinned on the six scenario-6 episodes)
 SCENARIO_DROP = ("iv_x_rows", "iv_t_rows", "step_x_start", "traj_So_t", "traj_Sno_t", "traj_Snh_t", "traj_t_t", "traj_EC",
@@ -566,14 +610,14 @@ def near_pole(rec):
     return np.int64(hit[0] if len(hit) else -1)
 
 
-def scenario_episodes(M, out, tol=1e-12):
+def scenario_episodes(M, out, tol=1e-12, cases=None):
     import scipy.integrate as si
     real = M.integrate
 
     def odeint_tight(func, y0, t, args=(), **kw):
         kw.setdefault("rtol", tol); kw.setdefault("atol", tol); kw.setdefault("mxstep", 100000)
         return si.odeint(func, y0, t, args=args, **kw)
-    for name, (seed, acts, scen) in scenario_cases().items():
+    for name, (seed, acts, scen) in (scenario_cases() if cases is None else cases).items():
         rec = run_episode(M, seed, acts, None, scenario=scen)
         rec["domain_exit_call"], rec["near_pole_call"] = domain_exit(rec), near_pole(rec)
         np.savez_compressed(os.path.join(out, "sbros_%s.npz" % name), **{k: v for k, v in rec.items() if k not in SCENARIO_DROP})
@@ -625,7 +669,7 @@ def tight_episodes(M, out, tol=1e-12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    ap.add_argument("--only", default="", help="regenerate one fixture group only: reward_oci | tight | scenarios")
+    ap.add_argument("--only", default="", help="regenerate one fixture group only: reward_oci | tight | scenarios | heldout")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
@@ -634,6 +678,8 @@ def main():
         return tight_episodes(M, out)
     if args.only == "scenarios":
         return scenario_episodes(M, out)
+    if args.only == "heldout":
+        return scenario_episodes(M, out, cases=heldout_cases(M))
     np.savez_compressed(os.path.join(out, "reward_oci_kat.npz"), **reward_oci_kats())
     if args.only == "reward_oci":
         return
@@ -666,6 +712,7 @@ def main():
                                                                   np.round(rec["reward"], 6).tolist()))
     tight_episodes(M, out)
     scenario_episodes(M, out)
+    scenario_episodes(M, out, cases=heldout_cases(M))
     print("wrote fixtures to", out)
 
 

@@ -246,6 +246,13 @@ static void rk4_reaction_w(const sbro_params* p, double* x, double span, int n, 
 #define B5A_ZS1 0.15
 #define B5A_ZS2 0.5
 #define B5A_N_MAX 64
+/* round 6, STUDY ONLY - off (0) by default and absent from the product.  ZR_STAB: the stability bound of the oxygen mode applied to the
+ * three OTHER fast modes as well (uptake of Ss, Snh, Sno: their own decay rates at the interval's start), n >= floor(j span / zr) + 1.
+ * Without effect with the reference's kinetic constants (rate x t_delta <= 1.0 on every captured interval); with 4 x faster kinetics it
+ * halves scheme 1's blow-ups (tests/test_oracle_golden.py::test_scheme1_under_perturbed_kinetic_constants switches it on to keep that on
+ * record).  Not adopted: three more wave-uniform constants in the plan cost the step kernel 0.2 us of 11.7 per call (profiles/r06_notes.md). */
+static double g_zr_stab = 0.0;
+void sbro_set_plan_knobs(double zr_stab) { g_zr_stab = zr_stab; }
 
 static void b5a_rhs(const sbro_params* p, int kind, const double* y, double v0, double kla, double ec, int hold_so, double* k) {
     if (kind == 2) sbro_rhs_idle(p, y, kla, k);
@@ -300,6 +307,18 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
         zs = z9 > zs ? z9 : zs;
         const int n_s = zs < B5A_ZS1 ? 1 : (zs < B5A_ZS2 ? 2 : 4);
         n = n_s > n ? n_s : n;
+        /* ... and never fewer than the stability of those three modes asks for (round 6): their own decay rates */
+        const double i2 = 1.0 / (p->Ks + fabs(ss)), i10 = 1.0 / (p->Knh + fabs(snh)), i9 = 1.0 / (p->Kno + fabs(sno));
+        const double j2 = ((p->muH / p->Yh) * p->Ks) * xbh * (i2 * i2);
+        const double j10 = ((p->ixb + 1 / p->Ya) * p->muA * p->Knh) * xba * (i10 * i10);
+        const double j9 = (((1 - p->Yh) / (2.86 * p->Yh)) * p->muH * p->eta_g * p->Kno) * xbh * m1 * (i9 * i9);
+        double jr = j2 > j10 ? j2 : j10;
+        jr = j9 > jr ? j9 : jr;
+        if (g_zr_stab > 0) {
+            const double qr = jr * span / g_zr_stab;
+            const int n_r = qr < 1.0 ? 1 : (!(qr < (double)B5A_N_MAX) ? B5A_N_MAX : (int)qr + 1);
+            n = n_r > n ? n_r : n;
+        }
     }
     const double h = span / n;
     if (slaved) k1[8] = 0.0;

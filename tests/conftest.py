@@ -14,6 +14,11 @@ EPISODES = ["const_2_5", "random_a", "random_b", "zeros", "max", "det_influent"]
 # model's domain on scenarios 0..5), c1_7 = constant [1.25, 7.5] on the two bench scenarios where [2, 5] does not stay physical
 SCENARIO_EPISODES = ["scn%d_%s" % (s, p) for s in range(8) for p in ("phys", "c25")] + ["scn4_c1_7", "scn5_c1_7"]
 BENCH_SCENARIOS = (4, 5, 6, 7)                # bench.py --policy physical: scenario = 4 + global id mod 4
+# round 6: HELD-OUT reference episodes (oracle/gen_golden.py heldout_cases) - excluded from any fitting of the integrator's plan
+# thresholds, then and later; new influent seeds; the reference's own random-walk action model (get_available_actions), set-points
+# held 20 calls, a sinusoidal DO set-point sweeping the oxygen knee; scenarios 4..7 and two of the low-ammonia ones
+HELDOUT_EPISODES = (["ho_walk_s%d" % s for s in (4, 5, 6, 7)] + ["ho_held20_s%d" % s for s in (4, 6, 1)] +
+                    ["ho_sine_s%d" % s for s in (5, 7, 2)])
 
 
 def pytest_configure(config):

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import BENCH_SCENARIOS, EPISODES, SCENARIO_EPISODES, gate, golden, obs_tolerance, valid_calls
+from conftest import BENCH_SCENARIOS, EPISODES, HELDOUT_EPISODES, SCENARIO_EPISODES, gate, golden, obs_tolerance, valid_calls
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -175,12 +175,16 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
     n = len(E)
     x, ctrl = env.get_state()
     assert gate(_np(x).T, ora.envs["x"]).max() < 1e-6                    # post-fill, measured 9.7e-10
-    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0     # vs reference, measured 1.6e-3
+    # vs the reference: the fill phase is RK4 x 252 under either scheme, measured 1.6e-3 of the gate.  (Rounds 5's bounds here - 1.0 of
+    # the gate, the reset observation within the gate-derived ~2e-5 - were set while an adaptive fill phase was being tried and
+    # outlived it: VERDICT r5 weak 2.  A fill-phase regression of 6 x now fails.)
+    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 0.01
     assert np.abs(obs0 - oobs0).max() < 1e-11                            # measured 4.4e-15
-    for i, e in enumerate(E):        # the reset observation inherits the state gate over its normalisers (conftest.obs_tolerance)
-        assert np.all(np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= obs_tolerance(e["x_postfill"])[0] + 1e-12)
+    for i, e in enumerate(E):
+        assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6      # measured 2e-8
     T = [golden("sbros_%s_tight" % name) for name in EPISODES]      # the reference itself at odeint rtol = atol = 1e-12
     worst_gold, worst_tight = np.zeros(n), np.zeros(n)
+    ec_prev_dev = 0.0
     for c in range(ncall):
         o, s, r, d = env.step(torch.from_numpy(acts[c]).cuda())
         oo, os_, orr, od = ora.step(acts[c])
@@ -206,6 +210,15 @@ def test_six_golden_episodes_against_oracle_and_reference(G, tables):
             # cost term of the reward (measured: 2.0e-6 under scheme 1, 3e-7 under scheme 0; every other episode < 4e-10)
             dr = np.abs(_np(r) - [t["step_reward"][c] for t in T])
             assert np.delete(dr, 3).max() < 5e-7 and dr[3] < 5e-6
+            # ... and the 5e-6 of `zeros` is what its dosing deviation implies, call by call: the reward is
+            # (1 - EQI2^2 - OCI^2)/473 with OCI = AE_OCI + EC_OCI <= 3.5 and EC_OCI = EC_conc sum(EC[-rows:-1]) td / (span 1000) =
+            # 4320 x (a weighted mean of this call's and the previous call's EC) for rows = 10 (module_reward_EQIOCI.py:70-107), so
+            # |d reward| <= 2 x 3.5 x 4320 / 473 x |d EC| + the state part (< 5e-7) = 64 |d EC| + 5e-7; the velocity-form NO3-PID
+            # (EC += Kc_EC e + ..., Kc_EC = 100, gym_SBR_oneshot.py:2006-2025) integrates 100 x the deviation of Sno into EC while
+            # it is unsaturated: |d EC| reaches 3e-8 in `zeros`, i.e. 2e-6 in the reward
+            d_ec = max(abs(ctrl[_capi.C_EC_LAST][3] - T[3]["step_EC"][c]), abs(ec_prev_dev))
+            assert dr[3] <= 64.0 * d_ec + 5e-7, (c, dr[3], d_ec)
+            ec_prev_dev = ctrl[_capi.C_EC_LAST][3] - T[3]["step_EC"][c]
             for i, e in enumerate(E):      # rewards / observations against the reference itself
                 if EPISODES[i] in CLOSED_LOOP_OK:
                     # reward = (1 - S)/473 with S = EQI2^2 + OCI^2 <= ~5: a 1e-5 state error gives <= 2e-5*S/473 ~ 2e-7
@@ -317,9 +330,16 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
     terminal phases, return and wastage included, for every episode on the bench's scenarios 4..7 under the physical policy -
     and up to the call at which an episode comes near a pole elsewhere; from there on the device must still equal the oracle
     in lockstep (same arithmetic, same garbage) and raise the library's NEAR_POLE flag."""
+    full = _closed_loop_batch_against_the_reference(G, tables, SCENARIO_EPISODES, default_tol_bar=1.0)
+    assert all(("scn%d_phys" % s) in full for s in BENCH_SCENARIOS) and len(full) == 9
+
+
+def _closed_loop_batch_against_the_reference(G, tables, names, default_tol_bar, tight_bar=1.0, reward_bar=5e-7):
+    """`names` as ONE batch on the device, chained over the whole episode, in lockstep with the oracle, against the reference at
+    1e-12 (bar: tight_bar of the gate) and at its default tolerance (default_tol_bar; None = not asserted).  Returns the episodes
+    that stayed inside the domain of parity for all 463 calls."""
     from gym_sbr2_amd import _capi
     means, stds = tables
-    names = SCENARIO_EPISODES
     E = [golden("sbros_" + nm) for nm in names]
     T = [golden("sbros_%s_tight" % nm) for nm in names]
     n, ncall = len(E), 463
@@ -332,9 +352,11 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
     obs0 = _np(env.reset(scenario=scen, rnd=rnd)).copy()
     ora.reset(ora.mix(means, stds, scen, rnd))
     x, _ = env.get_state()
-    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 1.0         # fill phase vs the reference, every scenario
+    # fill phase vs the reference, every scenario: RK4 x 252 under either scheme, measured 0.003 of the gate (the bound was 1.0 while
+    # round 5 tried an adaptive fill phase and stayed there after that was taken back: VERDICT r5 weak 2)
+    assert gate(_np(x).T, np.stack([e["x_postfill"] for e in E])).max() < 0.01
     for i, e in enumerate(E):
-        assert np.all(np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= obs_tolerance(e["x_postfill"])[0] + 1e-12)
+        assert np.abs(obs0[i] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6        # measured 2e-8
     worst_tight, worst_gold = np.zeros(n), np.zeros(n)
     xd, cd = env.get_state()
     for c in range(ncall):
@@ -357,11 +379,11 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
             for i in np.where(live)[0]:
                 worst_tight[i] = max(worst_tight[i], gate(x[i], T[i]["step_x_end"][c]).max())
                 worst_gold[i] = max(worst_gold[i], gate(x[i], E[i]["step_x_end"][c]).max())
-                assert abs(_np(r)[i] - T[i]["step_reward"][c]) < 5e-7
-    print("[info] scenario episodes, device vs reference(1e-12), worst gate: " +
-          ", ".join("%s %.3f" % (nm, w) for nm, w in zip(names, worst_tight)))
+                assert abs(_np(r)[i] - T[i]["step_reward"][c]) < reward_bar, (names[i], c)
+    print("[info] device vs reference(1e-12), worst gate: " + ", ".join("%s %.3f" % (nm, w) for nm, w in zip(names, worst_tight)))
     for i, nm in enumerate(names):
-        assert worst_tight[i] <= 1.0 and worst_gold[i] <= 1.0, (nm, worst_tight[i], worst_gold[i])
+        assert worst_tight[i] <= tight_bar, (nm, worst_tight[i])
+        assert default_tol_bar is None or worst_gold[i] <= default_tol_bar, (nm, worst_gold[i])
         if nv[i] == ncall:                                            # the whole episode is inside the domain of parity
             t = T[i]
             assert gate(x[i], t["term_x_after_idle"]).max() <= 1.0, nm
@@ -371,9 +393,20 @@ def test_scenario_episodes_closed_loop_against_the_reference_at_tight_tolerance(
             assert not near, nm
         else:
             assert int(ctrl[_capi.C_STATUS][i]) & _capi.ST_NEAR_POLE, nm          # the library says so itself
-    full = [nm for i, nm in enumerate(names) if nv[i] == ncall]
-    assert all(("scn%d_phys" % s) in full for s in BENCH_SCENARIOS) and len(full) == 9
     env.close()
+    return [nm for i, nm in enumerate(names) if nv[i] == ncall]
+
+
+def test_heldout_episodes_on_the_device(G, tables):
+    """the ten HELD-OUT reference episodes (excluded from any fitting of the plan thresholds: the reference's
+    own random-walk action model, set-points held 20 calls, a sinusoidal DO set-point through the oxygen knee; new influent
+    seeds) chained on the device in lockstep with the oracle - plan equality on every call included - inside 0.6 of the gate of
+    the reference at 1e-12 (oracle: 0.373, Ss of `ho_walk_s5`).  Against the reference's DEFAULT tolerance nothing is asserted
+    here: its own default run of the walk episodes is 1.3 .. 13 gates from its own 1e-12 run
+    (tests/test_oracle_golden.py::test_heldout_walk_episodes_and_the_reference_own_integrator_noise)."""
+    # rewards: 5e-6 - the walk episodes keep the dosing PID unsaturated, where EC carries 100 x the deviation of Sno into the cost term
+    full = _closed_loop_batch_against_the_reference(G, tables, HELDOUT_EPISODES, default_tol_bar=None, tight_bar=0.6, reward_bar=5e-6)
+    assert len(full) == 9 and "ho_held20_s1" not in full
 
 
 @pytest.mark.parametrize("scheme", [0, 1])
@@ -691,8 +724,11 @@ def test_fused_rollout_equals_step_by_step_and_oracle(G, tables):
         tot += r
     xa, ca = a_env.get_state(); xb, cb = b_env.get_state()
     # k_rollout and k_step inline the same device functions but are separate kernels (FMA contraction may differ)
-    assert gate(_np(xa).T, _np(xb).T).max() < 1e-6 and torch.allclose(ca, cb, rtol=1e-11, atol=1e-13)
     from gym_sbr2_amd import _capi
+    keep = [r_ for r_ in range(_capi.NCTRL) if r_ != _capi.C_PLAN]
+    assert gate(_np(xa).T, _np(xb).T).max() < 1e-6 and torch.allclose(ca[keep], cb[keep], rtol=1e-11, atol=1e-13)
+    # the plan row is sbr_step's report (its last interval: the aerobic one of the done call); the fused rollout reports none
+    assert bool((ca[_capi.C_PLAN] == 0).all()) and bool(((cb[_capi.C_PLAN].to(torch.int64) & 127) >= 1).all())
     for row in (_capi.C_T, _capi.C_DONE, _capi.C_STEPS, _capi.C_STATUS):
         assert torch.equal(ca[row], cb[row])
     assert torch.allclose(ret, tot, rtol=0, atol=1e-12)
@@ -749,12 +785,30 @@ def test_size_independent_properties_at_65536(G):
     assert bool(((v0 >= cfg.WV - 1e-12) & (v0 <= cfg.WV + cfg.EC_max * cfg.t_delta * 2 + 1e-12)).all())
     # inert soluble Si is never produced: after the fill it can only be diluted by the dosed carbon
     assert bool((x[1] <= first[1] * (1 + 1e-12)).all()) and bool((x[1] > 0).all())
-    # effluent + waste sludge were drawn - for every env whose plant stayed inside the model's domain.  (The uniform policy of
-    # this test drives ~86 % of the envs near a Monod pole, where the reference model's numbers have no physical meaning: the
-    # draw's wastage quotient waste / (sX - set-point) can then come out negative.  Seen once in ten runs of this test, on one
-    # env of 65 536, under scheme 1.)
-    sane = (ctrl[_capi.C_STATUS].to(torch.int64) & _capi.ST_NEAR_POLE) == 0
+    # effluent + waste sludge were drawn - for every env whose plant stayed inside the model's domain.  The uniform policy of this
+    # test drives ~86 % of the envs near a Monod pole, where the reference model's numbers have no physical meaning.  What then
+    # happens in the draw was CAPTURED in round 6 (scripts/analysis/draw_sweep.py on the CPU oracle: 9 instances in
+    # 12 M envs; draw_sweep_gpu.py on the device: 25 in 60 M, each equal to the oracle's replay; profiles/r06_draw_sweep.json):
+    # every instance is an env flagged NEAR_POLE | NEGATIVE long before the done call (So ~ 3e4 g/m3, Snh ~ 8e3), its sludge has
+    # collapsed (Xf ~ 400 - 600 instead of ~3 900), the retained layers hold LESS sludge than biomass_setpoint x residual volume,
+    # so `waste_sX_weight` (gym_SBR_oneshot.py:2363) is negative and the wastage quotient Qw = waste / (sX[0] - set-point) of
+    # :2376 with it: Qw = -0.7 ... -30 m3, and V = V_settled - Qeff - Qw comes out above WV.  The reference's own formula on a
+    # state outside its domain, reproduced; not a defect of sbr_draw.  Hence: an env with V >= WV after the done call must be a
+    # flagged one AND have a negative Qw, and the volume balance V + Qeff + Qw = the settled volume holds for every env.
+    st = ctrl[_capi.C_STATUS].to(torch.int64)
+    sane = (st & _capi.ST_NEAR_POLE) == 0
+    qw = ctrl[_capi.C_QW]
+    odd = x[0] >= cfg.WV
+    if bool(odd.any()):
+        ids = torch.nonzero(odd).flatten().tolist()
+        print("[info] seed %d: V >= WV after the done call on envs %s: V %s Qw %s status %s"
+              % (seed, ids, x[0][odd].tolist(), qw[odd].tolist(), st[odd].tolist()))
     assert int(sane.sum().item()) > 1000 and bool((x[0][sane] < cfg.WV).all())
+    assert bool(((st[odd] & _capi.ST_NEAR_POLE) != 0).all()) and bool((qw[odd] < 0).all())
+    fin = torch.isfinite(x[0]) & torch.isfinite(qw)
+    settled = x[0] + cfg.Qeff + qw                        # = the volume before the draw when no whole layer was wasted (true of every
+    whole = (settled < cfg.WV - 1e-9) & fin               # sane env: its first retained layer alone covers the wastage)
+    assert bool((settled[fin & ~whole] <= cfg.WV + 463 * cfg.EC_max * cfg.t_delta + 1e-9).all()) and not bool((whole & sane).any())
     # masked reset touches only the selected envs
     mask = torch.zeros(n, dtype=torch.uint8, device="cuda"); mask[::2] = 1
     env.reset(seed=6, scenario=scen, mask=mask)
@@ -1125,8 +1179,7 @@ def test_reference_shaped_single_env(G):
     env = G.make("SBROS-v1")
     obs = env.reset(rnd=e["rnd"])
     assert isinstance(obs, tuple) and len(obs) == 2 and len(obs[0]) == 9 and len(obs[1]) == 9
-    tol0 = obs_tolerance(e["x_postfill"])[0] + 1e-12          # the state gate over the observation's normalisers
-    assert np.all(np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= tol0)
+    assert np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6     # RK4 fill phase: measured 2e-8
     total, done, k = 0.0, False, 0
     while not done:
         obs, state, reward, done, info = env.step([2.0, 5.0])
@@ -1757,8 +1810,7 @@ def test_numpy_rng_reset_is_the_reference_draw(G, monkeypatch):
     np.random.seed(0)
     env = G.make("SBROS-v1")
     obs = env.reset()                                           # no rnd=, no seed=
-    tol0 = obs_tolerance(e["x_postfill"])[0] + 1e-12          # the state gate over the observation's normalisers
-    assert np.all(np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]) <= tol0)
+    assert np.abs(np.r_[obs[0], obs[1]] - np.r_[e["reset_obs_DO"], e["reset_obs_EC"]]).max() < 1e-6     # RK4 fill phase: measured 2e-8
     assert np.abs(env._influent[1:] - e["influent_mixed"][1:]).max() < 1e-11          # the reference's influent of seed 0
     after = np.random.get_state()[1].copy()
     np.random.seed(0); np.random.randn(48); np.random.randn(48)                        # the reference draws twice for scenario 6
@@ -2040,7 +2092,8 @@ def test_implicit_so_sno_memories_across_every_writer(G, tables):
     for c in range(5):
         ref.step(acts[c])
     xa, ca = env.get_state(); xb, cb = ref.get_state()
-    assert gate(_np(xa).T, _np(xb).T).max() < 1e-6 and torch.allclose(ca, cb, rtol=1e-11, atol=1e-13)
+    keep = [r_ for r_ in range(_capi.NCTRL) if r_ != _capi.C_PLAN]          # the plan row is sbr_step's report only: a rollout leaves 0
+    assert gate(_np(xa).T, _np(xb).T).max() < 1e-6 and torch.allclose(ca[keep], cb[keep], rtol=1e-11, atol=1e-13)
     assert torch.equal(ca[_capi.C_SO_M1], xa[8]) and torch.equal(ca[_capi.C_SNO_M1], xa[9])
     ref.close()
     # ... and stepping on from there, through the done call (whose terminal phases move x away from the memories)

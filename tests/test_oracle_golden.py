@@ -19,7 +19,7 @@ What is asserted, and why it is worded this way (measured numbers in DESIGN.md, 
 """
 import numpy as np
 import pytest
-from conftest import BENCH_SCENARIOS, EPISODES, SCENARIO_EPISODES, gate, golden, valid_calls
+from conftest import BENCH_SCENARIOS, EPISODES, HELDOUT_EPISODES, SCENARIO_EPISODES, gate, golden, valid_calls
 
 from oracle import sbr_oracle as O
 from oracle import sbr_params as P
@@ -27,7 +27,8 @@ from oracle import sbr_ref as R
 
 CLOSED_LOOP_OK = ["const_2_5", "random_a", "max", "det_influent"]
 CLOSED_LOOP_REFERENCE_NOISE = ["random_b", "zeros"]
-ALL_EPISODES = EPISODES + SCENARIO_EPISODES
+ALL_EPISODES = EPISODES + SCENARIO_EPISODES        # the 24 episodes the plan thresholds of cfg.scheme = 1 were fitted on (round 5)
+WITH_HELDOUT = ALL_EPISODES + HELDOUT_EPISODES     # + the ten held-out ones of round 6: identity tests run on all 34
 
 
 def _scn(e):
@@ -95,7 +96,7 @@ def test_interval_row_count_is_9_or_10():
     assert calc == n.tolist()
 
 
-@pytest.mark.parametrize("name", ALL_EPISODES)
+@pytest.mark.parametrize("name", WITH_HELDOUT)
 def test_layer1_lsoda_restatement_is_bit_identical_to_reference(name, tables):
     """Same LSODA, restated algorithm: every state, reward, observation and controller output of every
     call equals the reference's BIT FOR BIT (no tolerance), terminal phases included - on all eight influent scenarios
@@ -212,7 +213,7 @@ def test_pid_known_answers_open_loop(name, tables):
         assert clamped_hi > 0                      # the upper clamps (with anti-windup) are exercised
 
 
-@pytest.mark.parametrize("name", ALL_EPISODES)
+@pytest.mark.parametrize("name", WITH_HELDOUT)
 def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(name, tables):
     """Scheme 0 (RK4 x 10 per interval); scheme 1 has its own test below."""
     means, stds = tables
@@ -472,7 +473,7 @@ def _scheme1_params():
     return O.default_params(scheme=1)
 
 
-@pytest.mark.parametrize("name", ["const_2_5", "random_b", "zeros", "scn0_c25", "scn4_phys", "scn5_c25", "scn7_phys"])
+@pytest.mark.parametrize("name", ["const_2_5", "random_b", "zeros", "scn0_c25", "scn4_phys", "scn5_c25", "scn7_phys", "ho_walk_s5", "ho_sine_s7"])
 def test_scheme1_layer2_c_is_bit_identical_to_layer1(name, tables):
     means, stds = tables
     e = golden("sbros_" + name)
@@ -634,3 +635,126 @@ def test_scheme1_plan_on_states_far_from_the_reference_regime():
     assert (g1 > 1).sum() <= 1.35 * (g0 > 1).sum() + 5, ((g1 > 1).sum(), (g0 > 1).sum())          # measured 91 against 68
     assert np.percentile(g1, 99) < 8 and g1.max() < 200                                             # measured 4.3 and 39 (RK4 x 10: 5.8, 3 000)
     assert (g1[g0 < 0.1] > 30).sum() == 0                   # no blow-up where ten RK4 substeps are accurate (measured: worst 6.9)
+
+
+# ---------------------------------------------------------------------------------------------------- held-out episodes (round 6)
+@pytest.mark.parametrize("scheme", [1, 0])
+def test_heldout_episodes_open_and_closed_loop(scheme, tables):
+    """VERDICT r5 item 3(a).  The plan thresholds of cfg.scheme = 1 (0.3 / 1.0 / 2.5, the slaved test, two slaved steps) were fitted on
+    the 24 episodes of ALL_EPISODES; these ten reference episodes were captured AFTERWARDS and are excluded from any fitting
+    (oracle/gen_golden.py heldout_cases: new influent seeds, the reference's own random-walk action model through its
+    get_available_actions, set-points held 20 calls, a sinusoidal DO set-point sweeping the oxygen knee).  The bars are the fitted
+    set's: open loop (one interval from the reference's own state, against its LSODA end state) and closed loop (the whole chained
+    episode against the reference at odeint rtol = atol = 1e-12) within 0.6 of the gate.  Measured: scheme 1 open loop 0.222,
+    closed loop 0.373 (Ss of `ho_walk_s5`, call 52 - the episode on which the reference's OWN default-tolerance run is 13 gates
+    from its own 1e-12 run, see the next test); RK4 x 10: 0.470 and 0.254.  A value above 0.6 here is a finding to be
+    reported, not a reason to retune the thresholds on these episodes."""
+    means, stds = tables
+    p = O.default_params(scheme=scheme)
+    worst_open, worst_closed, worst_term = {}, {}, {}
+    for name in HELDOUT_EPISODES:
+        e, t = golden("sbros_" + name), golden("sbros_%s_tight" % name)
+        nv = min(valid_calls(e), valid_calls(t))
+        wo = 0.0
+        for i in range(len(e["iv_kind"])):
+            if e["iv_call"][i] > nv:
+                continue
+            span = float(e["iv_t_end"][i] - e["iv_t_start"][i])
+            x1, n = O.reaction_interval(e["iv_x_start"][i], span, float(e["iv_Kla"][i]), float(e["iv_EC"][i]), params=p, scheme=scheme)
+            wo = max(wo, gate(x1, e["iv_x_end"][i]).max())
+            assert n == -1 if scheme == 0 else 1 <= n <= 5
+        worst_open[name] = wo
+        b = O.OracleBatch(1, O.default_params(scheme=scheme))
+        b.reset(b.mix(means, stds, [_scn(e)], e["rnd"][None]))
+        assert gate(b.envs["x"][0], e["x_postfill"]).max() <= 0.01        # the fill phase (RK4 x 252 under either scheme): measured 0.003
+        wc = 0.0
+        for k in range(min(nv, 462)):
+            b.step(t["actions"][k][None])
+            wc = max(wc, gate(b.envs["x"][0], t["step_x_end"][k]).max())
+        worst_closed[name] = wc
+        if nv == 463:
+            b.step(t["actions"][462][None])
+            worst_term[name] = gate(b.envs["x"][0], t["term_x_after_idle"]).max()
+            assert abs(b.envs["ret"][0] / float(t["episode_return"]) - 1) < 1e-5 and abs(b.envs["qw"][0] / float(t["term_Qw"]) - 1) < 1e-5
+        else:
+            assert name == "ho_held20_s1" and nv == 295                   # the low-ammonia scenario leaves the domain of parity, as scn1_* do
+    print("[info] held-out episodes, cfg.scheme = %d: open loop worst %.3f (%s), closed loop vs the reference at 1e-12 worst %.3f (%s), "
+          "terminal state worst %.3f" % (scheme, max(worst_open.values()), max(worst_open, key=worst_open.get), max(worst_closed.values()),
+                                         max(worst_closed, key=worst_closed.get), max(worst_term.values())))
+    assert max(worst_open.values()) <= 0.6 and max(worst_closed.values()) <= 0.6 and max(worst_term.values()) <= 0.6
+
+
+def test_heldout_walk_episodes_and_the_reference_own_integrator_noise(tables):
+    """What the held-out random-walk episodes add to DESIGN.md 4.3's finding about `random_b` and `zeros`: under the reference's own
+    action model the NO3 set-point sits for long stretches where the dosing PID is unsaturated, and the closed loop amplifies
+    LSODA's default-tolerance error (1.5e-8 per interval) - the reference's default run of `ho_walk_s5` ends up 13 gates (Ss) from
+    its OWN run at 1e-12, `ho_walk_s6` / `ho_walk_s7` 1.3 gates.  No integrator other than the bit-identical LSODA run (layer 1)
+    can follow such a default-tolerance trajectory; the C oracle (either scheme) is as far from it as the reference's tight run
+    is, to 5 %, and inside the gate of the tight run (previous test)."""
+    means, stds = tables
+    for name, lo, hi in (("ho_walk_s5", 8.0, 20.0), ("ho_walk_s6", 1.0, 2.0), ("ho_walk_s7", 1.0, 2.0), ("ho_walk_s4", 0.0, 0.3)):
+        e, t = golden("sbros_" + name), golden("sbros_%s_tight" % name)
+        own = gate(t["step_x_end"][:462], e["step_x_end"][:462])
+        assert lo <= own.max() <= hi, (name, own.max())
+        for scheme in (1, 0):
+            b = O.OracleBatch(1, O.default_params(scheme=scheme))
+            b.reset(b.mix(means, stds, [_scn(e)], e["rnd"][None]))
+            xs = []
+            for k in range(462):
+                b.step(e["actions"][k][None])
+                xs.append(b.envs["x"][0].copy())
+            d = gate(np.array(xs), e["step_x_end"][:462])
+            assert d.max() <= 1.05 * own.max() + 0.4, (name, scheme, d.max(), own.max())
+            assert np.delete(d, 2, axis=1).max() <= max(1.0, 1.05 * np.delete(own, 2, axis=1).max() + 0.05)      # it is Ss (and what Ss drives)
+
+
+def test_scheme1_under_perturbed_kinetic_constants():
+    """the plan of cfg.scheme = 1 was validated with the reference's kinetic constants; what does it do for a
+    plant configured with FASTER kinetics (muH, muA, kh each up to 4 x), where every mode of the system is stiffer?  3 000 random
+    plant states with reference-like sludge (scripts/analysis/plan_probe.py), one interval each against RK4 x 1280, both schemes.
+    Measured: scheme 1 misses the gate on 134 states (11 beyond 30 gates), ten RK4 substeps on 420 (239 beyond 30 - their step
+    is fixed at h = dt, which is unstable once the oxygen rate times dt exceeds 2.785, while scheme 1's count grows with it).
+    Scheme 1 must not be worse than scheme 0 there.  The state-dependent stability floor for the Ss / Snh / Sno modes that
+    round 6 built and did not adopt (oracle study knob; 0.2 us per k_step call) would halve what is left: asserted too, so
+    that the number stays on record."""
+    import ctypes as C
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("plan_probe", os.path.join(ROOT, "scripts", "analysis", "plan_probe.py"))
+    pp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pp)
+    span = (0.25 + P.T_DELTA) - 0.25
+    knobs = O.lib().sbro_set_plan_knobs
+    knobs.argtypes = [C.c_double]
+
+    def run(guard):
+        rs = np.random.RandomState(3)
+        knobs(2.5 if guard else 0.0)
+        g1, g0 = [], []
+        try:
+            for _ in range(1500):
+                x, kla, ec = pp.sample(rs)
+                x[5], x[6] = rs.uniform(1500, 3000), rs.uniform(80, 200)
+                p1, p0 = O.default_params(scheme=1), O.default_params(scheme=0)
+                f = 10 ** rs.uniform(0, np.log10(4.0), 3)
+                for p in (p1, p0):
+                    p.muH *= f[0]; p.muA *= f[1]; p.kh *= f[2]
+                ex = O.rk4(0, x, span, 1280, kla, ec, params=p0)
+                if not (np.isfinite(ex).all() and (ex[[2, 4, 5, 8, 9, 10]] > -1e-9).all()):
+                    continue
+                x1 = O.reaction_interval(x, span, kla, ec, params=p1, scheme=1)[0]
+                g1.append(gate(x1, ex).max() if np.isfinite(x1).all() else 1e30)
+                r = O.rk4(0, x, span, 10, kla, ec, params=p0)
+                g0.append(gate(r, ex).max() if np.isfinite(r).all() else 1e30)
+        finally:
+            knobs(0.0)
+        return np.array(g1), np.array(g0)
+    g1, g0 = run(False)
+    assert len(g1) > 1350
+    print("[info] kinetic constants up to 4 x: scheme 1 misses the gate on %d of %d states (%d beyond 30 gates, worst %.3g); RK4 x 10 on %d "
+          "(%d beyond 30)" % ((g1 > 1).sum(), len(g1), (g1 > 30).sum(), g1.max(), (g0 > 1).sum(), (g0 > 30).sum()))
+    assert (g1 > 1).sum() <= 0.6 * (g0 > 1).sum() and (g1 > 30).sum() <= 0.2 * (g0 > 30).sum() + 2
+    g1g, _ = run(True)
+    print("[info] ... with the stability floor of the other modes (not adopted): %d (%d beyond 30, worst %.3g)" % ((g1g > 1).sum(), (g1g > 30).sum(), g1g.max()))
+    assert (g1g > 30).sum() <= (g1 > 30).sum() and g1g.max() <= g1.max()
