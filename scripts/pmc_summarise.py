@@ -95,7 +95,7 @@ with open(os.path.join(dst, "%s_bench_config2_kernel_stats.csv" % tag)) as f:
             KERNEL_TRACE = {"kernel": r["Name"].split("(")[0], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
                             "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "percentage_of_gpu_time": float(r["Percentage"]),
                             "file": "profiles/%s_bench_config2_kernel_stats.csv" % tag,
-                            "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (1852 steps = four "
+                            "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-large-leg (1852 steps = four "
                                        "episodes incl. their terminal calls; priming and warm-up launches included)"}
             break
 
@@ -140,7 +140,7 @@ out = {
     "unit_note": "counter values are KiB.  Both counters are calibrated in their own pass on eight %d-byte device-to-device "
                  "copies (__amd_rocclr_copyBuffer): WRITE_SIZE/bytes = %.4f, FETCH_SIZE/bytes = %.4f (gfx950 tallies 128-byte "
                  "fetches at 64 bytes, MI355X_MICROARCH.md HBM section)" % (CAL_BYTES, w_factor, f_factor),
-    "library_source_hash": lib_hash,
+    "library_source_hash": lib_hash, "policy": "physical",
     "envs_per_launch": n_envs, "kernel": short(step_k), "dispatches": len(fetch[step_k]),
     "FETCH_SIZE_raw_bytes": fetch_raw, "fetch_calibration_factor": f_factor, "write_calibration_factor": w_factor,
     "fetch_corrected_bytes": fetch_b, "WRITE_SIZE_bytes": write_b,

@@ -21,6 +21,6 @@ print("calibration: 8 device-to-device copies of %d bytes" % CAL_BYTES, file=sys
 # PMC_ENVS=n: the per-step workload alone at n envs per launch (e.g. 262144: the two-waves-per-SIMD build of k_step)
 envs = os.environ.get("PMC_ENVS")
 for workload, steps in ((("config2", "463"),) if envs else (("config2", "463"), ("config5", "463"), ("cycle", "4"))):
-    sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "20", "--workload", workload] + (
+    sys.argv = [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-large-leg", "--steps", steps, "--warmup", "20", "--workload", workload] + (
         ["--envs-per-gpu", envs] if envs else [])
     runpy.run_path(sys.argv[0], run_name="__main__")

@@ -15,7 +15,7 @@ mkdir -p $out
 # a committed profile only to a library with the same hash)
 python3 -c "from gym_sbr2_amd import build as b; b.build_library(); print(open(b.HASH).read().strip())" > $out/library_source_hash.txt
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_config2 -o run --output-format csv -- python3 bench.py --no-cpu-baseline > $out/bench_config2_profiled.json 2> $out/rocprof_trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace_config2 -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-large-leg > $out/bench_config2_profiled.json 2> $out/rocprof_trace.err
 echo "kernel trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_fetch -o run --output-format csv -- python3 scripts/pmc_workload.py > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 echo "FETCH_SIZE pass done"
@@ -51,7 +51,11 @@ for w in config2 config1 config5 cycle; do
   cp $out/bench_$w.json profiles/${tag}_bench_$w.json
   echo "bench $w: $(cut -c1-160 $out/bench_$w.json)"
 done
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_config2_driver_style.json 2> $out/bench_driver.err
+# SURVEY.md 8d's synthetic inputs (U[0, 8] x U[0, 15] on all eight scenarios) and the reference's own action model, as SECONDARY lines
+timeout -k 10 300 python3 bench.py --policy uniform --no-cpu-baseline --no-large-leg > profiles/${tag}_bench_config2_uniform.json 2> $out/bench_uniform.err
+timeout -k 10 300 python3 bench.py --policy walk --no-cpu-baseline --no-large-leg > profiles/${tag}_bench_config2_walk.json 2> $out/bench_walk.err
+echo "bench uniform: $(cut -c1-120 profiles/${tag}_bench_config2_uniform.json)"; echo "bench walk: $(cut -c1-120 profiles/${tag}_bench_config2_walk.json)"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $out/bench_config2_driver_style.json 2> $out/bench_driver.err
 cp $out/bench_config2_driver_style.json profiles/${tag}_bench_config2_driver_style.json
 echo "bench driver-style: $(cut -c1-160 $out/bench_config2_driver_style.json)"
 timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -2 > profiles/${tag}_pytest_gpu.log || true
