@@ -61,4 +61,7 @@ echo "bench driver-style: $(cut -c1-160 $out/bench_config2_driver_style.json)"
 timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tail -2 > profiles/${tag}_pytest_gpu.log || true
 echo "gpu tests: $(tail -1 profiles/${tag}_pytest_gpu.log)"
 mkdir -p $out/profiles && cp profiles/${tag}_* $out/profiles/
+# gpurun merges at most 64 MiB back: the raw per-dispatch tables of the passes have been distilled above
+rm -rf $out/trace_config2 $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/trace_n262144 $out/pmc_n262144
+du -sh $out | tail -1
 echo "profile_round $tag finished"
