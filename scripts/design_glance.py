@@ -35,14 +35,25 @@ def table(tag):
         m = re.search(r"(\d+) passed", open(log).read())
         gpu_tests = m.group(1) if m else "?"
     nb = {n: _j(tag, "bench_config2_n%d" % n) for n in (32768, 131072, 262144)}
+    uni, walk = _j(tag, "bench_config2_uniform"), _j(tag, "bench_config2_walk")
+    big, bigd = r2["larger_batches"]["262144"], rd["larger_batches"]["262144"]
+    fd = rd["fp64_valu"]["b5_steps_per_interval"]
     rows = [
         ("configs[2], `python bench.py` (%d steps = four episodes, resets and terminal calls inside; cfg.scheme = 1)" % c2["steps"],
          "**%.3ge9 env-steps/s**, %.2f µs per step; the same command with `--scheme 0` (ten RK4 substeps per interval, rounds 1-4) on the "
          "same box: %.3ge9, %.2f µs" % (c2["value"] / 1e9, c2["ms_per_step"] * 1e3, s0["value"] / 1e9, s0["ms_per_step"] * 1e3),
          "`%s_bench_config2.json`, `%s_bench_config2_scheme0.json`" % (tag, tag)),
-        ("configs[2], `--steps 20 --warmup 5` (the driver's command: calls 5-24 of an episode, all anoxic)",
+        ("configs[2], `--steps 20 --warmup 5` (the driver's command; since round 6 the timed calls are %d-%d of an episode: ten anoxic, the "
+         "double-step call 51, nine aerobic - until round 5 calls 5-24, all anoxic)" % (drv["config"]["timed_calls"][0], drv["config"]["timed_calls"][1] - 1),
          "%.3ge9 env-steps/s, %.2f µs per step, %.2f µs per launch by events" % (drv["value"] / 1e9, drv["ms_per_step"] * 1e3, rd["avg_launch_us"]),
          "`%s_bench_config2_driver_style.json`" % tag),
+        ("**262 144 envs on the one GPU, timed INSIDE the same command** (`roofline.larger_batches[\"262144\"]`, a second handle, the same bracket, "
+         "window and K; `%s`)" % bigd["kernel"],
+         "the driver's command: %.1f µs per step = **%.3f of the prescribed roofline by the wall clock** (%.3f by events), %.3ge9 env-steps/s; "
+         "`python bench.py` (four whole episodes, resets and terminal calls inside): %.1f µs = %.3f (%.3f by events), %.3ge9"
+         % (bigd["ms_per_step"] * 1e3, bigd["frac_wall"], bigd["frac_timed_launches"], bigd["env_steps_per_s"] / 1e9,
+            big["ms_per_step"] * 1e3, big["frac_wall"], big["frac_timed_launches"], big["env_steps_per_s"] / 1e9),
+         "`%s_bench_config2_driver_style.json`, `%s_bench_config2.json`" % (tag, tag)),
         ("`k_step<float,float,256,false,1,1>` per launch",
          "%.2f µs (`rocprofv3 --kernel-trace --stats`, %d calls, whole episodes), %.2f µs by events over the %d timed launches"
          % (kt["average_ns"] / 1e3, kt["calls"], r2["avg_launch_us"], r2["launches_timed"]), "`%s_bench_config2_kernel_stats.csv`" % tag),
@@ -58,11 +69,15 @@ def table(tag):
          "`%s_pmc_traffic.json`" % tag),
         ("`k_step` issue activity", "%.0f VALU instructions per wave and call (round 4, RK4: 3956); %s"
          % (pmc["valu_insts_per_wave"], pmc["sq_note"].split("; ", 1)[1]), "`%s_pmc_sq_by_kernel.csv`" % tag),
-        ("what the integrator does on this workload (CPU oracle's sample of it, same calls)",
-         "%.2f Butcher-5 steps per interval and env, %.2f per wavefront (its slowest lane's count); %.0f useful FLOP per env-step "
-         "(RK4 × 10: %d); carbon dosed in %.0f %% of the wave-calls"
-         % (f2["b5_steps_per_interval"]["per_env_mean"], f2["b5_steps_per_interval"]["per_wavefront_mean"], f2["flop_per_env_step"],
-            f2["b5_steps_per_interval"]["rk4_equivalent_flop"], 100 * c2["config"]["dosing_wave_call_share"]),
+        ("what the integrator does on this workload, **counted on the device** (round 6: the plan row `SBR_C_PLAN` of the timed envs, read "
+         "after each timed call in an untimed replay)",
+         "%.2f Butcher-5 steps per interval and env, %.2f per wavefront (its slowest lane's count; the CPU oracle's sample of the workload: "
+         "%.2f / %.2f); %.0f useful FLOP per env-step (RK4 × 10: %d); oxygen held (slaved) in %.0f %% of the env-calls; carbon dosed in %.0f %% "
+         "of the wave-calls.  The driver's calls 41-60: %.2f / %.2f"
+         % (f2["b5_steps_per_interval"]["per_env_mean"], f2["b5_steps_per_interval"]["per_wavefront_mean"],
+            f2["b5_steps_per_interval"]["cpu_oracle_sample"]["per_env_mean"], f2["b5_steps_per_interval"]["cpu_oracle_sample"]["per_wavefront_mean"],
+            f2["flop_per_env_step"], f2["b5_steps_per_interval"]["rk4_equivalent_flop"], 100 * f2["b5_steps_per_interval"]["slaved_share"],
+            100 * c2["config"]["dosing_wave_call_share"], fd["per_env_mean"], fd["per_wavefront_mean"]),
          "`roofline.fp64_valu`, `config` of `%s_bench_config2.json`" % tag),
         ("the no-overlap bound (one wave per SIMD)",
          "memory %.2f µs at 8 TB/s + arithmetic %.2f µs (anoxic call %.2f, aerobic %.2f: per-wave medians of the stamp build) + empty "
@@ -84,6 +99,15 @@ def table(tag):
                    % ("{:,}".format(n).replace(",", " "), b["value"] / 1e9, b["ms_per_step"] * 1e3, b["roofline"]["frac"])
                    for n, b in nb.items()),
          ", ".join("`%s_bench_config2_n%d.json`" % (tag, n) for n in nb)),
+        ("other policies, secondary lines (`--policy`; whole episodes, 65 536 envs)",
+         "`uniform` (SURVEY §8d's synthetic inputs: U[0, 8] × U[0, 15] on all eight scenarios): %.3ge9 env-steps/s, %.1f µs per step, %.0f %% of "
+         "the envs near a Monod pole at the end of an episode - under cfg.scheme = 1 the cost of a call depends on the states: %.2f × the physical "
+         "policy's throughput; `walk` (the reference's own action model, `get_available_actions`): %.3ge9, %.2f µs per step, %.2f steps per "
+         "wavefront (physical: %.2f)"
+         % (uni["value"] / 1e9, uni["ms_per_step"] * 1e3, 100 * uni["env_status"]["near_pole_frac_last_episode"], uni["value"] / c2["value"],
+            walk["value"] / 1e9, walk["ms_per_step"] * 1e3, walk["roofline"]["fp64_valu"]["b5_steps_per_interval"]["per_wavefront_mean"],
+            f2["b5_steps_per_interval"]["per_wavefront_mean"]),
+         "`%s_bench_config2_uniform.json`, `%s_bench_config2_walk.json`" % (tag, tag)),
         ("configs[1] (4 096 envs, fixed-step RK4 = cfg.scheme 0, 64 wavefronts: latency only)",
          "%.3ge8 env-steps/s, %.2f µs per launch" % (c1["value"] / 1e8, c1["roofline"]["avg_launch_us"]), "`%s_bench_config1.json`" % tag),
         ("CPU baseline on the GPU box (C port of the same algorithm, cfg.scheme = %d)" % cpu["scheme"],
@@ -109,10 +133,12 @@ def headline(tag):
     return ("* `SBROS-v1` — the step-level env (`SbrOS`): `sbr_reset` / `sbr_step` / fused `sbr_rollout`; **%.3ge9 env-steps/s** per step call at\n"
             "  65 536 envs on one MI355X (`python bench.py`, `profiles/%s_bench_config2.json`; with round 4's integrator, `--scheme 0`, on the same\n"
             "  box: %.3ge9), `k_step` %.2f µs per launch by the rocprof average of whole episodes = %.3f of the prescribed HBM roofline (round 4:\n"
-            "  13.32 µs, 0.315), and %.3ge10 in the fused rollout (the Python reference: %.0f env-steps/s per core, `oracle/time_reference.py`; its C\n"
-            "  port %.2ge6 on one core of the GPU box, %.2ge7 on %d)."
-            % (c2["value"] / 1e9, tag, s0["value"] / 1e9, kt["average_ns"] / 1e3, c2["roofline"]["frac_episode"], c5["value"] / 1e10, ref["value"],
-               cpu["single_thread"]["value"] / 1e6, cpu["value"] / 1e7, cpu["cores"]))
+            "  13.32 µs, 0.315); **262 144 envs on the same GPU, timed inside the same command: %.3f by the wall clock** (%.3ge9 env-steps/s); %.3ge10 in the\n"
+            "  fused rollout (the Python reference: %.0f env-steps/s per core, `oracle/time_reference.py`; its C port %.2ge6 on one core of the GPU\n"
+            "  box, %.2ge7 on %d)."
+            % (c2["value"] / 1e9, tag, s0["value"] / 1e9, kt["average_ns"] / 1e3, c2["roofline"]["frac_episode"],
+               c2["roofline"]["larger_batches"]["262144"]["frac_wall"], c2["roofline"]["larger_batches"]["262144"]["env_steps_per_s"] / 1e9,
+               c5["value"] / 1e10, ref["value"], cpu["single_thread"]["value"] / 1e6, cpu["value"] / 1e7, cpu["cores"]))
 
 
 def _replace_between(path, begin, end, text):
@@ -127,7 +153,7 @@ HL_BEGIN, HL_END = "<!-- headline:begin %s -->", "<!-- headline:end -->"
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     t = table(tag)
     if "--write" in sys.argv:
         _replace_between(os.path.join(ROOT, "DESIGN.md"), BEGIN % tag, END, t)

@@ -57,7 +57,7 @@ def test_design_glance_table_is_generated_from_the_committed_profiles():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
-    tag = "r05"
+    tag = "r06"
     begin = g.BEGIN % tag
     assert begin in text and g.END in text
     held = text[text.index(begin) + len(begin):text.index(g.END, text.index(begin))].strip()
