@@ -560,10 +560,25 @@ class StepLeg:
         gc.collect(); gc.disable()
         if self.dist_up:                            # the first barrier of a process group is slow (lazy connection set-up): not
             self.fence()                            # between priming and timing either
+        # clock priming, see the module docstring.  With a process group up every episode boundary issues the path's collective
+        # (the return all-gather), so the NUMBER of priming episodes must be the same on every rank: a loop that each rank ends by
+        # its own clock (as it was until round 6) lets ranks issue different numbers of collectives, after which the k-th
+        # collective of one rank pairs with another rank's (k+1)-th - a different operation - and RCCL hangs.  Found by the four-rank
+        # rehearsal of tests/test_gpu_parity.py; two ranks sharing one GPU had stayed in step by luck.  Every rank times its first
+        # priming episode, the slowest rank's time (one all-reduce) fixes the count for all.
         t_prime = time.perf_counter()
-        while time.perf_counter() - t_prime < PRIME_SECONDS:      # clock priming, see the module docstring
+        self.run(CALLS_PER_EPISODE, record=False)
+        torch.cuda.synchronize(self.dev)
+        n_more = None
+        if self.dist_up:
+            t_one = torch.tensor([time.perf_counter() - t_prime], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t_one, op=self.dist.ReduceOp.MAX)
+            n_more = max(0, int(PRIME_SECONDS / max(float(t_one.item()), 1e-4) + 0.5) - 1)
+        while (n_more > 0) if n_more is not None else (time.perf_counter() - t_prime < PRIME_SECONDS):
             self.run(CALLS_PER_EPISODE, record=False)
             torch.cuda.synchronize(self.dev)
+            if n_more is not None:
+                n_more -= 1
         t_primed = time.perf_counter()
         if self.state["in_episode"] == CALLS_PER_EPISODE:         # the advance, warm-up and timing start at the first call of an episode
             self.end_of_episode()
@@ -933,7 +948,8 @@ def main(argv=None):
     lb = None
     if world == 1 and args.envs_per_gpu is None and args.workload == "config2":
         lb = {}
-        for k_, v_ in (larger_batches(lib_hash) or {}).items():        # committed constants of this library, labelled as such
+        committed = (larger_batches(lib_hash) or {}) if (args.policy == "physical" and args.scheme is None) else {}    # they are lines of the default workload
+        for k_, v_ in committed.items():                               # committed constants of this library, labelled as such
             v_ = dict(v_, measured_in_this_run=False, committed_constant=True)
             lb[k_ if (k_ != str(LARGE_LEG_ENVS) or large is None) else k_ + "_committed_record"] = v_
         if large is not None:

@@ -59,16 +59,23 @@ def reference_randn(scenario):
 class SbrOS(_gym.Env):
     metadata = {"render.modes": ["human"]}                      # :101
 
-    def __init__(self, device=0, seed=None, reward=None, rng=None):
+    def __init__(self, device=0, seed=None, reward=None, rng=None, scheme=None):
         """rng: where reset() takes the 48 standard normals of the influent draw from when the caller passes neither `rnd` nor
         `influent`.  "numpy" - `np.random.randn(48)` on the host, once per reset, exactly the reference's draw
         (buffer_tank3.py:68): `np.random.seed(k)` before reset() selects the episode, as with the reference.  "philox" - drawn on
-        the device from `seed` + episode count.  Default: "numpy", or "philox" when a `seed` is given."""
+        the device from `seed` + episode count.  Default: "numpy", or "philox" when a `seed` is given.
+        scheme: cfg.scheme of the library (None = its default, 1: adaptive Butcher-5 per interval; 0: ten RK4 substeps - the scheme
+        whose nodes trajectory(dense=True) replays, so that its dense rows ARE the integrator's own intermediate states)."""
         # the reference declares stale spaces (:106-113); these are the real ones of step()
         self.action_space = _gym.box([0.0, 0.0], [8.0, 15.0])
         self.observation_space = _gym.box(np.full(18, -np.inf), np.full(18, np.inf))
         # reward: None / "eqi_oci" = the reference's (module_reward_EQIOCI.py); "g2anet", "oci" = the other reward modules
-        self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64, reward=reward)
+        cfg = None
+        if scheme is not None:
+            from .. import _capi
+            cfg = _capi.default_config()
+            cfg.scheme = int(scheme)
+        self._vec = SbrOSVec(1, device=device, out_dtype=torch.float64, action_dtype=torch.float64, reward=reward, config=cfg)
         views = self._vec.enable_host_io()        # the kernel reads the action from, and writes its outputs to, pinned host memory
         self._act_row, self._obs_row, self._state_row = views[0][0], views[1][0], views[2][0]
         self._reward_view, self._done_view = views[3], views[4]

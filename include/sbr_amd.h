@@ -318,7 +318,13 @@ int sbr_eval_rhs(sbr_env* env, int32_t kind, int64_t n, const double* x, const d
  * interpolation onto any grid.  kind 0: a control interval (reaction_dxdt :1658-1787, ec [n] held); 1: the fill phase
  * (filling_dxdt :1424-1583, loading [n][14] with loading[0] = the inflow); 2: the idle phase (idle_dxdt :2424-2552); 3: settle
  * and draw (Sim_Settling_Drawing :2264-2420) applied to x0 first, then the idle phase - node 0 is the reactor after the draw.
- * ec may be NULL unless kind == 0, loading unless kind == 1.  DEVICE pointers.  Not on the stepping path. */
+ * ec may be NULL unless kind == 0, loading unless kind == 1.  DEVICE pointers.  Not on the stepping path.
+ * The nodes are RK4's under EITHER cfg.scheme.  Under cfg.scheme = 0 they are the states sbr_step itself passed through (the last
+ * node equals its end state to 1e-12).  Under cfg.scheme = 1 sbr_step integrated the interval with adaptive Butcher-5 steps: the
+ * replayed rows are then another discretisation of the same interval from the same start state - inside the parity gate of the
+ * reference's rows like the stepped states, but their last node differs from the state sbr_step returned by the two schemes'
+ * distance (~1e-2 of the gate; up to 2e-5 relative after the idle phase).  A consumer that needs rows ending exactly on the
+ * stepped states pins the last row to the record (gym_sbr2_amd's trajectory(dense=True) does) or runs cfg.scheme = 0. */
 int sbr_eval_substeps(sbr_env* env, int32_t kind, int64_t n, int32_t n_sub, const double* x0, const double* kla, const double* ec,
                       const double* loading, const double* h, double* xs, double* dxs, void* stream);
 
