@@ -666,6 +666,18 @@ def tight_episodes(M, out, tol=1e-12):
         M.integrate = real
 
 
+def cycle_heldout(out):
+    """Round 6: eight HELD-OUT cycles of the per-cycle env SBR-v2 (the five of sbrv2_cycles.npz were what round 5 fitted and checked the
+    adaptive integrator on).  Another seed; DO set-points INSIDE the oxygen knee (action x 8 < 0.7 g/m3: the PID then holds dissolved
+    oxygen where its uptake rate is stiffest, for hundreds of intervals), around it, and seeded random ones."""
+    rs = np.random.RandomState(606)
+    acts = np.array([[0.05, 0.05, 0.05], [0.02, 0.08, 0.5], [0.3, 0.06, 0.04], [0.9, 0.5, 0.07], [0.12, 0.1, 0.09]] +
+                    rs.uniform(0, 1, (3, 3)).tolist())
+    rec = run_cycle_env(acts, seed=31)
+    np.savez_compressed(os.path.join(out, "sbrv2_cycles_heldout.npz"), **rec)
+    print("SBR-v2 held-out: %d cycles, rewards %s" % (len(acts), np.round(rec["reward"], 6).tolist()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -679,7 +691,8 @@ def main():
     if args.only == "scenarios":
         return scenario_episodes(M, out)
     if args.only == "heldout":
-        return scenario_episodes(M, out, cases=heldout_cases(M))
+        scenario_episodes(M, out, cases=heldout_cases(M))
+        return cycle_heldout(out)
     np.savez_compressed(os.path.join(out, "reward_oci_kat.npz"), **reward_oci_kats())
     if args.only == "reward_oci":
         return
@@ -713,6 +726,7 @@ def main():
     tight_episodes(M, out)
     scenario_episodes(M, out)
     scenario_episodes(M, out, cases=heldout_cases(M))
+    cycle_heldout(out)
     print("wrote fixtures to", out)
 
 

@@ -10,8 +10,12 @@ from oracle.sbr_cycle_ref import SbrEnv2Ref
 from oracle.sbr_ref import influent_mix
 
 
-def test_layer1_lsoda_is_bit_identical_to_reference(tables):
-    g = golden("sbrv2_cycles")
+FIXTURES = ["sbrv2_cycles", "sbrv2_cycles_heldout"]      # the second (round 6): eight held-out cycles, set-points inside the oxygen knee
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_layer1_lsoda_is_bit_identical_to_reference(tables, fixture):
+    g = golden(fixture)
     env = SbrEnv2Ref(tables)
     assert g["ph_n_intervals"][:6].tolist() == [24, 48, 223, 186, 11, 36]
     for c in range(len(g["actions"])):
@@ -26,6 +30,9 @@ def test_layer1_lsoda_is_bit_identical_to_reference(tables):
         assert np.array_equal(env.sx, g["sX"][c]) and env.qw == g["Qw"][c] and env.eqi == g["EQI"][c]
         assert np.array_equal(env.eff, g["eff"][c]) and np.array_equal(env.x_after_draw, g["x_after_draw"][c])
         assert np.array_equal(st, g["state"][c]) and r == g["reward"][c]
+    if fixture == "sbrv2_cycles_heldout":
+        assert len(g["actions"]) == 8 and g["reward"][0] < -10 and (g["actions"][:5] * 8 < 1.0).any(axis=1).all()    # set-points in the knee
+        return
     assert g["reward"][1] < -10 and g["reward"][0] > 0       # the ammonia penalty (no aeration) is exercised
     # clipping (gym_SBR_env2.py:133): the fifth cycle was run with [1.7, -0.3, 0.5]; [1, 0, 0.5] must give the same cycle
     assert g["actions"][4].tolist() == [1.7, -0.3, 0.5]
@@ -34,9 +41,10 @@ def test_layer1_lsoda_is_bit_identical_to_reference(tables):
     assert np.array_equal(st, g["state"][4]) and r == g["reward"][4]
 
 
-def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables):
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables, fixture):
     means, stds = tables
-    g = golden("sbrv2_cycles")
+    g = golden(fixture)
     py = SbrEnv2Ref(tables, integrator="rk4")
     for c in range(len(g["actions"])):
         st0 = py.reset(g["rnd"][c])
@@ -52,17 +60,19 @@ def test_layer2_c_rk4_is_bit_identical_to_layer1_rk4(tables):
         assert np.array_equal(diag[3:8], py.eff[1:])
 
 
+@pytest.mark.parametrize("fixture", FIXTURES)
 @pytest.mark.parametrize("scheme", [0, 1])
-def test_rk4_cycle_inside_gate_of_reference(tables, scheme):
+def test_rk4_cycle_inside_gate_of_reference(tables, scheme, fixture):
     """RK4 with 10 substeps per control interval (scheme 0) and the adaptive Butcher-5 of round 5 (scheme 1: every interval) against the reference's LSODA, closed loop over the whole cycle.
     Measured: phase-end states <= 0.018 of the gate, rewards within 3.2e-8, Qw within 1.7e-7 relative (scheme 0)."""
     means, stds = tables
-    g = golden("sbrv2_cycles")
+    g = golden(fixture)
     n = len(g["actions"])
     b = O.OracleCycleBatch(n, O.default_params(scheme=scheme), nthreads=2)
     b.reset(np.stack([influent_mix(means[0], stds[0], g["rnd"][c]) for c in range(n)]))
     st, r, diag = b.step(g["actions"])
     last = g["ph_x_end"][g["phase_first"] + 5]
+    print("[info] %s, cfg.scheme = %d: cycle-end state worst %.4f of the gate, rewards within %.1e" % (fixture, scheme, gate(b.x, last).max(), np.abs(r - g["reward"]).max()))
     assert gate(b.x, last).max() <= 0.1
     assert np.abs(r - g["reward"]).max() < 1e-6 and np.abs(diag[:, 0] / g["Qw"] - 1).max() < 1e-5
     assert np.allclose(st, g["state"], rtol=1e-6, atol=1e-7) and np.abs(diag[:, 1] / g["EQI"] - 1).max() < 1e-6

@@ -1016,13 +1016,14 @@ def test_multi_cycle_carry_over_against_oracle(G, tables):
     env.close()
 
 
-def test_cycle_env_sbr_v2_against_oracle_and_reference(G, tables):
+@pytest.mark.parametrize("fixture", ["sbrv2_cycles", "sbrv2_cycles_heldout"])
+def test_cycle_env_sbr_v2_against_oracle_and_reference(G, tables, fixture):
     """`SBR-v2`: one step() = one whole 12 h cycle in one launch.  The five reference cycles (float64
-    actions incl. an out-of-range one), then 256 envs with random influent/scenarios/actions against the C oracle,
-    then a carried-over second cycle."""
+    actions incl. an out-of-range one) - and (round 6) eight HELD-OUT ones whose DO set-points sit inside the oxygen knee -, then
+    256 envs with random influent/scenarios/actions against the C oracle, then a carried-over second cycle."""
     from gym_sbr2_amd import _capi
     means, stds = tables
-    g = golden("sbrv2_cycles")
+    g = golden(fixture)
     n = len(g["actions"])
     env = G.SbrEnv2Vec(n, out_dtype=torch.float64, action_dtype=torch.float64)
     obs0 = _np(env.reset(rnd=g["rnd"])).copy()
