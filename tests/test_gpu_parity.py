@@ -86,7 +86,22 @@ def test_native_library_is_loaded_and_fails_loudly_on_bad_config(G):
     big.close()
     with pytest.raises(ValueError):
         env.step(torch.zeros(3, 2))
+    # the call counter shares a row with the plan code, the flags and the status bits (an integer below 2^31 held in a double): it
+    # saturates at 2^17 - 1 calls per episode (until round 6: 2^25 - 1; an episode of the reference has 463), an imported value
+    # beyond that is clamped, the plan code beside it is kept (0 .. 255), and stepping on neither wraps nor disturbs the flags
+    env.reset(seed=1)
+    x_s, c_s = env.get_state()
+    c_s[_capi.C_STEPS] = torch.tensor([5.0, 131070.0, 131071.0, 1e9], dtype=torch.float64, device="cuda")
+    c_s[_capi.C_PLAN] = torch.tensor([0.0, 4.0, 130.0, 999.0], dtype=torch.float64, device="cuda")
+    env.set_state(x_s, c_s)
+    _, c_r = env.get_state()
+    assert _np(c_r[_capi.C_STEPS]).tolist() == [5, 131070, 131071, 131071] and _np(c_r[_capi.C_PLAN]).tolist() == [0, 4, 130, 255]
+    env.step(torch.full((4, 2), 2.0, device="cuda")); env.step(torch.full((4, 2), 2.0, device="cuda"))
+    _, c_r = env.get_state()
+    assert _np(c_r[_capi.C_STEPS]).tolist() == [7, 131071, 131071, 131071] and _np(c_r[_capi.C_DONE]).tolist() == [0, 0, 0, 0]
+    assert _np(c_r[_capi.C_STATUS]).tolist() == [0, 0, 0, 0] and np.all((_np(c_r[_capi.C_PLAN]).astype(int) & 127) >= 1)
     # an env that was never reset is inert: done = 1, reward 0
+    env.close(); env = G.SbrOSVec(4)
     _, _, r, d = env.step(torch.zeros(4, 2))
     assert _np(d).tolist() == [1, 1, 1, 1] and _np(r).tolist() == [0, 0, 0, 0]
     # nulls at the ABI: every output of sbr_step is optional, the action is not; bad rows are refused with a message
