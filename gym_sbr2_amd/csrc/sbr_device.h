@@ -494,7 +494,16 @@ SBR_DEV int sbr_b5a(const SbrPar& p, double (&x)[SBR_NX], double span, double kl
     const bool slaved = (fabs(so) < 1e-9) && (kla_sat * span < 1e-9);
     // n = 2 (slaved) / 1 / 2 / the knee: max(4, floor(lam(0) span / 2.5) + 1), capped at 64 so that every wave terminates
     const double qn = lam0 * span * (1.0 / 2.5);
-    const int n_knee = qn < 4.0 ? 4 : (!(qn < 64.0) ? 64 : (int)qn + 1);
+    // ... for a state INSIDE the model's domain.  The count grows with lam(0) because a1 and a3 are bounded there (the Monod factors of
+    // Ss and Snh lie in [0, 1]); outside - Ss or Snh negative towards or beyond its pole, or NaN - the premise is gone, the state is
+    // garbage (the reference has no guards either; SBR_ST_NEAR_POLE says so) and the count stays at the knee's four: a launch lasts as
+    // long as its slowest wavefront, and ONE such lane at 64 steps made a 65 536-env launch take 60 us instead of 11 (round 6: the
+    // uniform policy's late-episode calls 27 us, its done call up to 3 ms).  No in-domain state is affected.
+    // (written as two selects on qn, each consuming its comparison at once: a combined lane mask would live in scalar registers across
+    // the plan, and the fused kernels' step loops pay for scalar pressure with spill moves.  A NaN factor fails its comparison.)
+    const double qn1 = fabs(m1 - 0.5) <= 0.5 ? qn : 0.0;
+    const double qn2 = fabs(m3 - 0.5) <= 0.5 ? qn1 : 0.0;
+    const int n_knee = qn2 < 4.0 ? 4 : (!(qn2 < 64.0) ? 64 : (int)qn2 + 1);
     const int n_z = slaved ? 2 : (z_ub < 0.3 ? 1 : (z_ub < 1.0 ? 2 : n_knee));
     // ... and never fewer steps than the other Monod arguments ask for: |slope| span / (K + |x|) of Ss, Snh, Sno
     const double f2 = p.Ks + fabs(ss), f10 = p.Knh + fabs(snh), f9 = p.Kno + fabs(a[A_SNO]);

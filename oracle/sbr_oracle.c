@@ -298,6 +298,11 @@ static int b5a_macro(const sbro_params* p, int kind, double* x, double span, dou
     else {                                  /* the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39) */
         const double q = lam0 * span / B5A_Z_STAB;
         n = q < 4.0 ? 4 : (!(q < (double)B5A_N_MAX) ? B5A_N_MAX : (int)q + 1);
+        /* ... for a state inside the model's domain: there a1 and a3 are bounded (the Monod factors of Ss and Snh lie in [0, 1]).
+         * Outside - Ss or Snh negative towards or beyond its pole, or NaN - the premise is gone and the state is garbage (the reference
+         * has no guards either): the count stays at the knee's four, so that one such env cannot make a whole batch wait for its 64
+         * steps (round 6).  No in-domain state is affected. */
+        if (!(fabs(m1 - 0.5) <= 0.5 && fabs(m3 - 0.5) <= 0.5)) n = 4;          /* (also true for NaN) */
     }
     {   /* how far the arguments of the other Monod terms move within the interval */
         double zs = fabs(k1[2]) * span / (p->Ks + fabs(ss));

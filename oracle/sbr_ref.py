@@ -238,6 +238,10 @@ def b5a_plan(x, k1, span, kla):
     else:                                   # the knee: at least four steps, and lam(0) h <= Z_STAB (Butcher-5: stable to 3.39)
         q = lam0 * span / B5A_Z_STAB
         n = 4 if q < 4.0 else (B5A_N_MAX if not (q < float(B5A_N_MAX)) else int(q) + 1)
+        # ... for a state inside the model's domain, where a1 and a3 are bounded (Monod factors in [0, 1]); outside (Ss or Snh negative
+        # towards or beyond its pole, or NaN) the state is garbage and the count stays at the knee's four (see oracle/sbr_oracle.c)
+        if not (abs(m1 - 0.5) <= 0.5 and abs(m3 - 0.5) <= 0.5):
+            n = 4
     # how far the arguments of the other Monod terms move within the interval: |slope| span / (K + |x|)
     zs = abs(k1[2]) * span / (P.KS + abs(ss))
     z10 = abs(k1[10]) * span / (P.KNH + abs(snh))

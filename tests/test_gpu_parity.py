@@ -725,6 +725,32 @@ def test_status_flags_report_leaving_the_physical_domain(G):
     env.reset(rnd=np.zeros((n, 48)))
     assert _np(env.status()).tolist() == [0] * n                      # cleared by reset
     env.close()
+    # Round 6: a state OUTSIDE the model's domain does not raise the step count.  The knee's count grows with the oxygen rate at
+    # So = 0 - up to 64 steps - because inside the domain that rate is bounded by the Monod factors of Ss and Snh; with Ss beyond its
+    # pole (Ss < -K_S: factor 21) or a NaN the "rate" is garbage, and ONE such lane at 64 steps made a 65 536-env launch last 60 us
+    # instead of 11 (the uniform policy's late calls; its done call 3 ms).  Aerobic interval from So = 0 (the knee), Kla > 0:
+    m = 6
+    i = int(np.where(e["iv_kind"] == 1)[0][0])
+    x = np.tile(e["iv_x_start"][i][:, None], (1, m))
+    ctrl = np.zeros((_capi.NCTRL, m))
+    ctrl[_capi.C_T] = e["iv_t_start"][i]
+    ctrl[_capi.C_SO_M1] = ctrl[_capi.C_SO_M2] = x[8, 0]
+    ctrl[_capi.C_SNO_M1] = ctrl[_capi.C_SNO_M2] = x[9, 0]
+    x[5, 1] *= 3.0; x[6, 1] *= 3.0       # in the domain, three times the biomass: the stability rule asks for more than four steps
+    x[5, 2] *= 1e6                       # in the domain (absurd biomass): the cap of 64
+    x[2, 3] = -10.5                      # Ss beyond its pole at -K_S = -10: Monod factor 21
+    x[10, 4] = float("nan")              # NaN ammonia
+    x[10, 5] = -1.2                      # Snh beyond its pole at -K_NH = -1: factor 6
+    env = G.SbrOSVec(m, out_dtype=torch.float64, action_dtype=torch.float64)
+    env.set_state(x, ctrl)
+    env.step(torch.tensor([[2.0, 5.0]] * m, dtype=torch.float64))
+    steps = (_np(env.plan()) & 127).tolist()
+    assert steps[0] == 4 and 5 <= steps[1] <= 14 and steps[2] == 64 and steps[3:] == [4, 4, 4], steps
+    ora = O.OracleBatch(m)
+    ora.load_state(x, ctrl)
+    ora.step(np.tile([2.0, 5.0], (m, 1)))
+    assert (ora.envs["scheme_plan"] & 127).tolist() == steps          # the oracle applies the same rule
+    env.close()
 
 
 def test_fused_rollout_equals_step_by_step_and_oracle(G, tables):

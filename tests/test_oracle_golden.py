@@ -557,6 +557,16 @@ def test_scheme1_takes_more_steps_where_four_would_be_unstable():
     assert O.reaction_interval(x0, span, kla, 0.0, scheme=0)[1] == -1
     x0[5] *= 1e6                                                       # absurd: the count is capped, the call returns
     assert O.reaction_interval(x0, span, kla, 0.0)[1] == 64
+    # round 6: ... and a state OUTSIDE the model's domain (the Monod factor of Ss or Snh outside [0, 1], or NaN) does not raise the
+    # count at all: the premise of the stability rule - an oxygen rate bounded by those factors - is gone, the state is garbage, and
+    # one such env at 64 steps would make a whole batch wait for it (a launch lasts as long as its slowest wavefront)
+    for idx, val in ((2, -10.5), (2, -1e3), (10, -1.2), (10, float("nan")), (2, float("nan"))):
+        xg = e["iv_x_start"][i].copy()
+        xg[5] *= 3.0; xg[6] *= 3.0
+        xg[idx] = val
+        assert O.reaction_interval(xg, span, kla, 0.0)[1] == 4, (idx, val)
+    xg = e["iv_x_start"][i].copy(); xg[5] *= 3.0; xg[6] *= 3.0; xg[10] = -1e-300       # a rounding-level negative counts as inside
+    assert 5 <= O.reaction_interval(xg, span, kla, 0.0)[1] <= n2
 
 
 def test_scaled_mass_rk4_equals_concentration_form_rk4_far_below_the_truncation_error():
