@@ -154,6 +154,12 @@ typedef struct sbr_config {
                                   ..._plan_on_states_far_from_the_reference_regime).  A configuration with kinetics several
                                   times faster than the reference's or a longer t_delta is outside what either scheme was
                                   validated on: check it against a fine solution (sbr_eval_substeps with many substeps) first.
+                                  OUTSIDE THE MODEL'S DOMAIN (the Monod factor of Ss or Snh outside [0, 1]: a concentration
+                                  negative towards or beyond its pole, or NaN - SBR_ST_NEAR_POLE is then set or about to be) the
+                                  oxygen rate is no longer bounded and the step count is NOT raised above the knee's four: the
+                                  state is garbage either way (the reference has no guards), and a launch lasts as long as its
+                                  slowest wavefront - one such env at the cap of 64 steps made a whole 65 536-env batch
+                                  several times slower (round 6).  In-domain states are unaffected.
                                   What scheme 1 did is observable per env and call: SBR_C_PLAN, SBR_TR_PLAN. */
     int32_t reserved_;         /* keeps the struct a multiple of 8 bytes; MUST be 0: sbr_create rejects anything else with
                                   SBR_ERR_INVALID (round 6), so that a later round can give the word a meaning */
