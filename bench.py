@@ -611,9 +611,10 @@ class StepLeg:
                 "timed_calls": [c for lo, hi in self.acct["call_ranges"] for c in range(lo, hi)]}
 
     def device_plan_counts(self, calls):
-        """What cfg.scheme = 1 did on THIS leg's envs, counted on the device (round 6): one more episode with the same seeds,
-        actions and call order as the timed ones (untimed, eager), reading the plan row (SBR_C_PLAN: step count and slaved bit of
-        each env's last interval) after every call of `calls`.  Returns per-env and per-wavefront means over those calls."""
+        """What cfg.scheme = 1 did on THIS leg's envs, counted on the device (round 6): one more episode of the same envs (the next
+        reset seed, the same action rows and call order as the timed ones; untimed, eager), reading the plan row (SBR_C_PLAN: step
+        count and slaved bit of each env's last interval) after every call of `calls`.  Returns per-env and per-wavefront means over
+        those calls."""
         torch, capi = self.torch, self.capi
         if not hasattr(capi, "C_PLAN") or not calls:
             return None
@@ -639,7 +640,7 @@ class StepLeg:
         k = float(len(want))
         return {"per_env_mean": lane_sum / k, "per_wavefront_mean": wave_sum / k, "slaved_share": slaved_sum / k,
                 "dosing_wave_call_share": dose_sum / k, "calls_counted": len(want), "envs_counted": self.n_local,
-                "source": "device: SBR_C_PLAN / SBR_C_EC_LAST read after each of the timed calls in a replay of the same episode (untimed)"}
+                "source": "device: SBR_C_PLAN / SBR_C_EC_LAST read after each of those calls in one more, untimed episode of the same envs with the same action rows"}
 
     def close(self):
         self.env.close()
@@ -884,7 +885,7 @@ def main(argv=None):
                                           "flop_per_step": FP64_FLOP_PER_B5_STEP, "rk4_equivalent_flop": SUBSTEPS * FP64_FLOP_PER_SUBSTEP["plain"]},
                 "anoxic_share_of_timed_calls": frac_anoxic,
                 "note": "cfg.scheme = 1: Butcher-5 step loops only, counted in the ISA (FMA = 2); the step counts are the DEVICE's own "
-                        "(the plan row of the timed envs, read after each timed call in an untimed replay of the same episode); "
+                        "(the plan row of the timed envs, read after each of the timed calls in one more, untimed episode of the same envs); "
                         "scheme 0 spent 4300 FLOP per env-step on the same intervals"}
     else:
         # scheme 0: the RK4 substep loops only, ALL counted at the closed-reactor loop's 426 FLOP per substep - a lower bound.  A

@@ -70,7 +70,7 @@ def table(tag):
         ("`k_step` issue activity", "%.0f VALU instructions per wave and call (round 4, RK4: 3956); %s"
          % (pmc["valu_insts_per_wave"], pmc["sq_note"].split("; ", 1)[1]), "`%s_pmc_sq_by_kernel.csv`" % tag),
         ("what the integrator does on this workload, **counted on the device** (round 6: the plan row `SBR_C_PLAN` of the timed envs, read "
-         "after each timed call in an untimed replay)",
+         "after each of those calls in one more, untimed episode of the same envs)",
          "%.2f Butcher-5 steps per interval and env, %.2f per wavefront (its slowest lane's count; the CPU oracle's sample of the workload: "
          "%.2f / %.2f); %.0f useful FLOP per env-step (RK4 × 10: %d); oxygen held (slaved) in %.0f %% of the env-calls; carbon dosed in %.0f %% "
          "of the wave-calls.  The driver's calls 41-60: %.2f / %.2f"
