@@ -189,8 +189,11 @@ class SbrOSVec:
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
+        # capture_error_mode "thread_local": only THIS thread's calls are checked against the capture.  With a process group up,
+        # RCCL's watchdog thread polls its events from another thread, which the default ("global") mode may take for an illegal call
+        # during capture and invalidate the graph - in a multi-rank run, of all places.  sbr_step itself makes no such call.
         with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 for a in actions:
                     self.step(a)
         torch.cuda.current_stream(self.device).wait_stream(side)
