@@ -610,11 +610,12 @@ class StepLeg:
                 "host_issue_ms": (t_issued - t0) * 1e3, "gap_ms": gap_ms, "resets_timed": self.state["episode"] - episodes_before,
                 "timed_calls": [c for lo, hi in self.acct["call_ranges"] for c in range(lo, hi)]}
 
-    def device_plan_counts(self, calls):
+    def device_plan_counts(self, calls, actions=None):
         """What cfg.scheme = 1 did on THIS leg's envs, counted on the device (round 6): one more episode of the same envs (the next
         reset seed, the same action rows and call order as the timed ones; untimed, eager), reading the plan row (SBR_C_PLAN: step
         count and slaved bit of each env's last interval) after every call of `calls`.  Returns per-env and per-wavefront means over
-        those calls."""
+        those calls.  `actions` [calls, N, 2]: step through these rows instead of the pool (the fused rollout's own on-device draws,
+        returned by sbr_rollout's actions_out: sbr_step with them passes through the rollout's states, to rounding)."""
         torch, capi = self.torch, self.capi
         if not hasattr(capi, "C_PLAN") or not calls:
             return None
@@ -626,7 +627,7 @@ class StepLeg:
         full = self.n_local - self.n_local % 64
         ec = torch.empty(self.n_local, dtype=torch.float64, device=self.dev)
         for c in range(max(want) + 1):
-            self.env.step(self.pool_rows[c % self.n_rows])
+            self.env.step(self.pool_rows[c % self.n_rows] if actions is None else actions[c])
             if c in want:
                 self.env.ctrl_row(capi.C_PLAN, out=row)
                 p = row.to(torch.int64)
@@ -640,7 +641,10 @@ class StepLeg:
         k = float(len(want))
         return {"per_env_mean": lane_sum / k, "per_wavefront_mean": wave_sum / k, "slaved_share": slaved_sum / k,
                 "dosing_wave_call_share": dose_sum / k, "calls_counted": len(want), "envs_counted": self.n_local,
-                "source": "device: SBR_C_PLAN / SBR_C_EC_LAST read after each of those calls in one more, untimed episode of the same envs with the same action rows"}
+                "source": ("device: SBR_C_PLAN / SBR_C_EC_LAST read after each of those calls in one more, untimed episode of the same envs "
+                           "with the same action rows" if actions is None else
+                           "device: SBR_C_PLAN / SBR_C_EC_LAST read after each call of one more, untimed episode stepped through sbr_step with "
+                           "the actions the fused rollout's on-device policy draws (sbr_rollout's actions_out)")}
 
     def close(self):
         self.env.close()
@@ -856,6 +860,13 @@ def main(argv=None):
     counts = None
     if scheme == 1 and not fused and rank == 0:
         counts = leg.device_plan_counts(sorted(set(timed_calls))[:CALLS_PER_EPISODE])
+    elif scheme == 1 and fused and rank == 0:
+        # the fused kernel reports no plan (its state never leaves the registers): take the actions its policy draws for one more
+        # episode and step through sbr_step with them - the same states to rounding, and the plan row says what each interval took
+        leg.reset()
+        _, racts = env.rollout(CALLS_PER_EPISODE, policy_seed=77, return_actions=True)
+        counts = leg.device_plan_counts(list(range(CALLS_PER_EPISODE)), actions=racts)
+        del racts
     # The CPU baseline (rank 0 of a 1-GPU run), after the timed region.  Its first pass also counts what the integrator did on
     # ITS sample of the workload (other random draws): kept as a cross-check of the device's count.
     cpu = cpu_baseline(policy=args.policy, scheme=scheme) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
