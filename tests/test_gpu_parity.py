@@ -910,6 +910,52 @@ def test_bench_workload_parity_at_65536_with_the_physical_policy(G, tables):
     env.close()
 
 
+def test_bench_walk_policy_workload_at_65536_against_oracle(G, tables):
+    """`bench.py --policy walk` (the reference's own action model, get_available_actions gym_SBR_oneshot.py:440-459: from [0, 15]
+    every call moves each set-point by -0.1 / 0 / +0.1 and -5 / 0 / +5 inside [0, 8] x [0, 15]) on the bench's 65536 envs against
+    the oracle, free-running over the whole episode on a 512-env sample.  With the aeration set-point walking near 0 a few
+    percent of the envs end an episode near a Monod pole (SBR_ST_NEAR_POLE; the reference model has no guards): those are
+    excused from the state comparison, as in the configs[1] test, and must carry the same flags on both sides."""
+    import bench
+    from gym_sbr2_amd import _capi
+    means, stds = tables
+    n = 65536
+    pick = np.r_[0:192, n // 2:n // 2 + 128, n - 192:n]
+    scen = (4 + np.arange(n) % 4).astype(np.int32)
+    env = G.SbrOSVec(n)
+    obs = _np(env.reset(seed=1000, scenario=scen)).copy()
+    ora = O.OracleBatch(len(pick))
+    z = np.stack([O.OracleBatch(1, first_env_id=int(i)).normals(1000)[0] for i in pick])
+    oobs = ora.reset(ora.mix(means, stds, scen[pick], z))
+    assert np.abs(obs[pick] - oobs).max() < 1e-5
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    cur = torch.tensor([0.0, 15.0], device="cuda").repeat(n, 1)
+    ret, moved = np.zeros(len(pick)), 0
+    for c in range(463):
+        nxt = bench.walk_move(cur, torch.randint(0, 3, (n, 2), device="cuda", generator=gen), torch)
+        moved += int((nxt != cur).any(dim=1).sum().item())
+        cur = nxt
+        assert float(cur.min().item()) >= 0.0 and float(cur[:, 0].max().item()) <= 8.0 and float(cur[:, 1].max().item()) <= 15.0
+        o, s_, r, d = env.step(cur)
+        oo, os_, orr, od = ora.step(_np(cur)[pick].astype(np.float64))
+        ret += orr
+        assert np.array_equal(_np(d)[pick], od)
+    assert moved > 0.5 * n * 463                                     # the walk walks
+    x, ctrl = env.get_state()
+    ctrl = _np(ctrl)
+    st, ost = ctrl[_capi.C_STATUS].astype(np.int64), ora.envs["status"].astype(np.int64)
+    assert np.all((st & _capi.ST_NONFINITE) == 0)
+    pole = ((st[pick] | ost) & _capi.ST_NEAR_POLE) != 0
+    assert pole.mean() < 0.2 and ((st & _capi.ST_NEAR_POLE) != 0).mean() < 0.1, (pole.mean(), ((st & _capi.ST_NEAR_POLE) != 0).mean())
+    ok = ~pole
+    assert np.array_equal(st[pick][ok], ost[ok])
+    g = gate(_np(x).T[pick][ok], ora.envs["x"][ok]).max()
+    assert g < 1e-6, g                                                # free-running over 463 calls, every well-posed sampled env
+    assert np.all(ctrl[_capi.C_DONE] == 1) and np.abs(ctrl[_capi.C_RETURN][pick][ok] - ret[ok]).max() < 1e-9
+    print("bench workload (walk policy), free-running sample: %d of %d sampled envs well-posed, worst gate %.3e" % (ok.sum(), len(pick), g))
+    env.close()
+
+
 def test_configs3_per_gpu_shape_against_oracle_and_the_unsharded_batch(G, tables):
     """BASELINE.json configs[3] at ITS OWN per-GPU shape: rank 3 of 8 of a 262144-env batch = 32768 envs with global ids
     98304..131071, which run in the 64-thread-workgroup build of k_step (SBR_SMALL_BATCH).  66 calls under the physical policy,
